@@ -1,0 +1,157 @@
+/* mnmf.h -- C-ABI of the MI355X-native NMF multiplicative-update engine.
+ *
+ * Drop-in boundary for MANTA's solver hot path.  The reference has no FFI: its seam is the
+ * Python function run_nmf (manta/_functions/nmf/nmf_orchestrator.py:143).  Each entry point
+ * below names the reference interface it replaces; manta_amd/nmf.py is the Python binding
+ * with the reference signature (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no exceptions cross the boundary.
+ *  - every function returns MNMF_OK (0) or a negative mnmf_status; mnmf_last_error(ctx)
+ *    returns the text for the last failure on that context.
+ *  - "device pointer" = HIP device memory on the context's GPU, caller-owned.
+ *  - factor layouts are the reference's: W is m x k row-major, H is k x V row-major,
+ *    S is k x k row-major, element type = the context dtype (f32 or f64).
+ *  - all work is enqueued on the context's stream; the run_* functions return after the
+ *    stream has drained (blocking, like the reference).
+ *  - one host thread per context; a context is bound to one GPU.
+ */
+#ifndef MNMF_H
+#define MNMF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mnmf_ctx mnmf_ctx;
+
+typedef enum {
+  MNMF_OK = 0,
+  MNMF_EINVAL = -1, /* bad argument / shape */
+  MNMF_EHIP = -2,   /* HIP runtime error */
+  MNMF_ECOMM = -3,  /* the all-reduce hook failed */
+  MNMF_ENAN = -4,   /* non-finite convergence norm */
+  MNMF_ESTATE = -5  /* call out of order (e.g. run before set_matrix) */
+} mnmf_status;
+
+enum { MNMF_F32 = 0, MNMF_F64 = 1 };
+
+/* Solver options.  A negative value (or 0 for the int fields marked so) selects the
+ * reference's hard-coded constant for the method:
+ *   nmf : max_iter 10000 (-> <=10001 updates), eps 1e-10           nmf_basic.py:26-27,57
+ *   pnmf: max_iter 1000, norm_thresh 0.005, eps 1e-10, zero 1e-10  nmf_projective_basic.py:37-50
+ *   nmtf: max_iter 1000 (-> <=1001 updates), eps 1e-9              nmtf.py:128,204           */
+typedef struct {
+  int32_t max_iter;       /* <0: reference default */
+  int32_t fixed_iters;    /* >0: apply exactly this many updates and skip the convergence test */
+  int32_t check_every;    /* convergence test every n iterations; <=0 -> 1 (the reference tests every iteration).
+                             Ignored when fixed_iters>0 unless force_check is set. */
+  int32_t force_check;    /* with fixed_iters: still compute the norms every check_every iterations */
+  int32_t finalize;       /* 1: apply the reference's post-loop thresholds / normalisation; 0: raw factors */
+  int32_t profile_phases; /* 1: bracket every kernel class with HIP events and fill mnmf_stats.phase_ms */
+  double norm_thresh;     /* <0: 0.005 (what both pipelines pass, modeling_pipeline.py:65) */
+  double eps;             /* <0: reference default */
+  double zero_threshold;  /* <0: 1e-5 (run_nmf default, nmf_orchestrator.py:143); pnmf: 1e-10 */
+} mnmf_opts;
+
+typedef struct {
+  int32_t iters;          /* updates applied to the returned factors */
+  int32_t converged;      /* 1 if the reference's stopping rule fired before max_iter */
+  double w_norm, h_norm, s_norm; /* last norms computed (spectral for nmf/pnmf, Frobenius for nmtf) */
+  double ms_total;        /* wall time of the loop (host clock, stream drained) */
+  double ms_kernels;      /* HIP-event time around the loop on the context's stream */
+  double bytes_model;     /* algorithmic HBM bytes per iteration, SURVEY.md section 8(d) */
+  double flops_model;     /* algorithmic flops per iteration */
+  /* HIP-event time per kernel class, summed over the loop (profile_phases=1), in ms:
+   * 0 Gram of W (m rows)   1 SpMM X^T.W   2 H-side products + update   3 Gram of H / k x k chains
+   * 4 SpMM X.H^T           5 W-side update                6 convergence norms      7 unused */
+  double phase_ms[8];
+} mnmf_stats;
+
+/* Sum-all-reduce hook for document-sharded runs (one process per GPU).  Called by the solvers
+ * at their exchange points with a device pointer inside the exchange buffer, an element count
+ * and the context dtype; must leave the summed values in place, ordered after prior work on
+ * `stream` and before later work on it.  Return 0 on success.  No counterpart in the reference
+ * (it is single-process); the Python side implements it with torch.distributed (RCCL). */
+typedef int (*mnmf_allreduce_fn)(void* user, void* dev_ptr, int64_t count, int dtype, void* stream);
+
+/* -- lifetime ---------------------------------------------------------------------------- */
+/* Create a context on GPU `device`, computing in `dtype`, enqueuing on `hip_stream`
+ * (a hipStream_t; NULL = the default stream). */
+int mnmf_create(mnmf_ctx** out, int device, int dtype, void* hip_stream);
+void mnmf_destroy(mnmf_ctx* ctx);
+const char* mnmf_last_error(const mnmf_ctx* ctx);
+const char* mnmf_version(void);
+
+/* Install (or clear, fn==NULL) the all-reduce hook.  `n_ranks` is informational (byte model). */
+int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ranks);
+
+/* -- the matrix -------------------------------------------------------------------------- */
+/* Give the engine this rank's rows of X as CSR (replaces `in_mat.tocsr()` being handed to the
+ * solvers, nmf_orchestrator.py:116).  rowptr: int64[m+1]; colidx: int32[nnz], ascending inside a
+ * row; vals: dtype[nnz].  on_device!=0: the three arrays are device pointers, else host.
+ * The engine copies them, builds X^T and its streaming layouts, and keeps everything resident
+ * until the next set_matrix / destroy; the caller keeps ownership of its buffers. */
+int mnmf_set_matrix(mnmf_ctx* ctx, int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr,
+                    const int32_t* colidx, const void* vals, int on_device);
+
+/* -- solvers (device pointers, reference layouts, updated in place) ------------------------ */
+/* Loop A, replaces _basic_nmf (nmf_basic.py:6-93).  W: m x k in/out, H: k x V in/out. */
+int mnmf_run_nmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats);
+/* Loop B, replaces projective_nmf (nmf_projective_basic.py:8-121).  W: in/out, H: out only
+ * (= W^T X with the L2-column-normalised W when opts->finalize). */
+int mnmf_run_pnmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats);
+/* Loop C, replaces _core_nmtf_test (nmtf/nmtf.py:123-216).  W, S (k x k), H all in/out. */
+int mnmf_run_nmtf(mnmf_ctx* ctx, int k, void* W, void* S, void* H, const mnmf_opts* opts,
+                  mnmf_stats* stats);
+
+/* -- kernel-level entry points (tests, benchmarks, profiling) ------------------------------ */
+/* out = X . B (transpose==0; B: V x k, out: m x k) or X^T . B (transpose!=0; B: m x k, out: V x k);
+ * the expressions `in_mat @ h.T` (nmf_basic.py:45) and `w.T @ in_mat` (nmf_basic.py:40, as its
+ * transpose).  Row-major, leading dimension k. */
+int mnmf_spmm(mnmf_ctx* ctx, int transpose, int k, const void* B, void* out);
+/* out (k x k) = A^T . B over `rows` rows (B==NULL: A^T A): `w.T @ w` (nmf_basic.py:39),
+ * `h @ h.T` (:44, on H^T), `W.T @ pay` (nmf_projective_basic.py:75). */
+int mnmf_gram(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, void* out);
+/* out = A * (num / (A . G + eps))  (sqrt_mode: A * sqrt(num / (A . G + num . G2 + eps))):
+ * the fused numerator/denominator/eps update of nmf_basic.py:41-42,46-47 and
+ * nmf_projective_basic.py:76-79.  A, num, out: rows x k; G, G2: k x k. */
+int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* num, const void* G,
+                const void* G2, double eps, int sqrt_mode, void* out);
+/* sigma_max(|A - B|) (norm_kind 0, `norm_func(np.abs(w - w_old), 2)`, nmf_basic.py:52) or its
+ * Frobenius norm (norm_kind 1, nmtf.py:179) for rows x k matrices. */
+int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind,
+                   double* out);
+/* Asynchronous device-to-device copy on the context's stream.  No counterpart in the reference;
+ * lets a Python all-reduce hook stage an exchange buffer it only knows by address. */
+int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes);
+
+/* -- host-only helpers (no GPU needed; used by the CPU tests) ------------------------------ */
+/* Build the streaming-segment description of a CSR row pointer exactly as set_matrix does.
+ * Outputs are malloc'ed arrays the caller frees with mnmf_free_host.  See DESIGN.md "stream layout". */
+typedef struct {
+  int64_t n_seg;       /* segments */
+  int64_t* seg_start;  /* [n_seg+1] nnz offsets */
+  int32_t* seg_info;   /* [n_seg] >=0: index into nzrow of the first row; <0: ~carry slot (chunk of a long row) */
+  int64_t n_nzrow;
+  int32_t* nzrow;      /* ids of non-empty rows, ascending */
+  int64_t n_empty;
+  int32_t* empty_rows; /* ids of empty rows */
+  int64_t n_fix;       /* long rows that were chunked */
+  int32_t* fix_row;    /* [n_fix] row id */
+  int32_t* fix_first;  /* [n_fix] first carry slot */
+  int32_t* fix_count;  /* [n_fix] number of carry slots */
+  int64_t n_carry;
+} mnmf_segments;
+int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t long_row,
+                        mnmf_segments* out);
+void mnmf_free_segments(mnmf_segments* s);
+/* lambda_max of a symmetric n x n matrix (row-major, double) by cyclic Jacobi. */
+double mnmf_sym_lambda_max(const double* a, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNMF_H */

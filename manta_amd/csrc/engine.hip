@@ -1,0 +1,1027 @@
+// mnmf engine: context, resident matrix, the three MU solver loops and the C-ABI (include/mnmf.h).
+// gfx950 only.  Host orchestration is deliberately thin: every numeric expression of the reference
+// loops runs in a HIP kernel from spmm.hpp / dense.hpp / gram_mfma.hpp.
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/mnmf.h"
+#include "common.hpp"
+#include "dense.hpp"
+#include "eig.hpp"
+#include "sparse_prep.hpp"
+#include "spmm.hpp"
+
+using namespace mnmf;
+
+struct ImplBase {
+  virtual ~ImplBase() {}
+  virtual int set_matrix(int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                         const void* vals, int on_device) = 0;
+  virtual int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
+  virtual int run_pnmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
+  virtual int run_nmtf(int k, void* W, void* S, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
+  virtual int k_spmm(int transpose, int k, const void* B, void* out) = 0;
+  virtual int k_gram(int64_t rows, int k, const void* A, const void* B, void* out) = 0;
+  virtual int k_update(int64_t rows, int k, const void* A, const void* num, const void* G, const void* G2,
+                       double eps, int sqrt_mode, void* out) = 0;
+  virtual int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) = 0;
+};
+
+struct mnmf_ctx {
+  int device = 0;
+  int dtype = MNMF_F32;
+  hipStream_t stream = nullptr;
+  std::string err;
+  mnmf_allreduce_fn ar = nullptr;
+  void* ar_user = nullptr;
+  int n_ranks = 1;
+  ImplBase* impl = nullptr;
+  void fail(int, const std::string& msg) { err = msg; }
+};
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes; else p = nullptr;
+    return e;
+  }
+  template <typename U>
+  U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+struct PhaseTimer {
+  // HIP events on the solver's stream at phase boundaries; summed after the loop has drained.
+  static constexpr int kMaxPhases = 8;
+  hipStream_t s;
+  bool on;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> tag;  // phase that ENDS at this event (-1 = start marker)
+  PhaseTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {}
+  ~PhaseTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+  void mark(int phase) {
+    if (!on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    ev.push_back(e);
+    tag.push_back(phase);
+  }
+  void collect(double* out /*kMaxPhases*/) {
+    for (int i = 0; i < kMaxPhases; ++i) out[i] = 0.0;
+    for (size_t i = 1; i < ev.size(); ++i) {
+      if (tag[i] < 0 || tag[i] >= kMaxPhases) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) out[tag[i]] += ms;
+    }
+  }
+};
+
+template <typename T>
+struct StreamMat {
+  int64_t rows = 0, tab_rows = 0, nnz = 0;  // out rows, gather-table rows
+  DevBuf cols, vals;                         // uint32 (flagged), T
+  std::vector<int64_t> h_rowptr;
+  // segment description for the current seg_q
+  int64_t seg_q = -1, n_seg = 0, n_nzrow = 0, n_empty = 0, n_fix = 0, n_carry = 0;
+  DevBuf seg_start, seg_info, nzrow, empty_rows, fix_row, fix_first, fix_count, carry;
+};
+
+inline int pow2_ceil(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+template <typename T>
+class Engine : public ImplBase {
+ public:
+  explicit Engine(mnmf_ctx* c) : ctx(c) {}
+  ~Engine() override {
+    if (h_pinned) (void)hipHostFree(h_pinned);
+  }
+
+  mnmf_ctx* ctx;
+  int64_t m = 0, V = 0, nnz = 0;
+  bool have_matrix = false;
+  StreamMat<T> X, Xt;
+  // solver workspaces
+  DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD;
+  double* h_pinned = nullptr;
+  size_t h_pinned_cap = 0;
+  double phase_ms[PhaseTimer::kMaxPhases] = {0};
+
+  hipStream_t st() const { return ctx->stream; }
+  static int ld_of(int k) { return (int)round_up(k, 4); }
+
+  int fail(int code, const std::string& msg) {
+    ctx->fail(code, msg);
+    return code;
+  }
+#define E_HIP(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return fail(MNMF_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__) + " (engine.hip:" +   \
+                                 std::to_string(__LINE__) + ")");                                     \
+  } while (0)
+#define E_LAUNCH() E_HIP(hipGetLastError())
+
+  int pinned(size_t doubles) {
+    if (doubles <= h_pinned_cap) return 0;
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    h_pinned = nullptr;
+    h_pinned_cap = 0;
+    E_HIP(hipHostMalloc((void**)&h_pinned, doubles * sizeof(double), hipHostMallocDefault));
+    h_pinned_cap = doubles;
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ matrix
+  int set_matrix(int64_t m_, int64_t V_, int64_t nnz_, const int64_t* rowptr, const int32_t* colidx,
+                 const void* vals, int on_device) override {
+    have_matrix = false;
+    if (m_ < 0 || V_ <= 0 || nnz_ < 0 || !rowptr) return fail(MNMF_EINVAL, "set_matrix: bad shape");
+    if (nnz_ > 0 && (!colidx || !vals)) return fail(MNMF_EINVAL, "set_matrix: null arrays");
+    if (nnz_ >= (int64_t)1 << 31 || m_ >= (int64_t)1 << 31 || V_ >= (int64_t)1 << 31)
+      return fail(MNMF_EINVAL, "set_matrix: per-rank m, V and nnz must be below 2^31 (shard the rows)");
+    E_HIP(hipSetDevice(ctx->device));
+    m = m_;
+    V = V_;
+    nnz = nnz_;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    X.h_rowptr.assign(m + 1, 0);
+    if (on_device) {
+      E_HIP(hipMemcpyAsync(X.h_rowptr.data(), rowptr, (m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st()));
+      E_HIP(hipStreamSynchronize(st()));
+    } else {
+      std::memcpy(X.h_rowptr.data(), rowptr, (m + 1) * sizeof(int64_t));
+    }
+    if (X.h_rowptr[0] != 0 || X.h_rowptr[m] != nnz) return fail(MNMF_EINVAL, "set_matrix: rowptr[0] must be 0 and rowptr[m] == nnz");
+    for (int64_t r = 0; r < m; ++r)
+      if (X.h_rowptr[r + 1] < X.h_rowptr[r]) return fail(MNMF_EINVAL, "set_matrix: rowptr not monotone");
+    X.rows = m;
+    X.tab_rows = V;
+    X.nnz = nnz;
+    X.seg_q = -1;
+    Xt.rows = V;
+    Xt.tab_rows = m;
+    Xt.nnz = nnz;
+    Xt.seg_q = -1;
+    Xt.h_rowptr.assign(V + 1, 0);
+    const size_t n = (size_t)std::max<int64_t>(nnz, 1);
+    E_HIP(X.cols.ensure(n * 4));
+    E_HIP(X.vals.ensure(n * sizeof(T)));
+    E_HIP(Xt.cols.ensure(n * 4));
+    E_HIP(Xt.vals.ensure(n * sizeof(T)));
+    if (nnz == 0) {
+      have_matrix = true;
+      return 0;
+    }
+    E_HIP(hipMemcpyAsync(X.cols.p, colidx, nnz * 4, kind, st()));
+    E_HIP(hipMemcpyAsync(X.vals.p, vals, nnz * sizeof(T), kind, st()));
+    DevBuf d_rp, d_trp, rowid, iota, keys_out, perm, tmp, d_max;
+    E_HIP(d_rp.ensure((m + 1) * 8));
+    E_HIP(d_trp.ensure((V + 1) * 8));
+    E_HIP(rowid.ensure(n * 4));
+    E_HIP(iota.ensure(n * 4));
+    E_HIP(keys_out.ensure(n * 4));
+    E_HIP(perm.ensure(n * 4));
+    E_HIP(hipMemcpyAsync(d_rp.p, X.h_rowptr.data(), (m + 1) * 8, hipMemcpyHostToDevice, st()));
+    const int TB = 256;
+    expand_rowids_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(d_rp.template as<int64_t>(), m, nnz, rowid.template as<uint32_t>(),
+                                                                   iota.template as<uint32_t>());
+    E_LAUNCH();
+    // validate column ids before anything gathers through them
+    {
+      size_t bytes = 0;
+      E_HIP(d_max.ensure(4));
+      E_HIP(rocprim::reduce(nullptr, bytes, X.cols.template as<uint32_t>(), d_max.template as<uint32_t>(), 0u, (size_t)nnz,
+                            rocprim::maximum<uint32_t>(), st()));
+      E_HIP(tmp.ensure(bytes));
+      E_HIP(rocprim::reduce(tmp.p, bytes, X.cols.template as<uint32_t>(), d_max.template as<uint32_t>(), 0u, (size_t)nnz,
+                            rocprim::maximum<uint32_t>(), st()));
+      uint32_t mx = 0;
+      E_HIP(hipMemcpyAsync(&mx, d_max.p, 4, hipMemcpyDeviceToHost, st()));
+      E_HIP(hipStreamSynchronize(st()));
+      if ((int64_t)mx >= V) return fail(MNMF_EINVAL, "set_matrix: column index out of range");
+    }
+    // stable sort of nnz by column: rows stay ascending inside each column of X^T
+    {
+      int bits = 1;
+      while (((int64_t)1 << bits) < V) ++bits;
+      size_t bytes = 0;
+      E_HIP(rocprim::radix_sort_pairs(nullptr, bytes, X.cols.template as<uint32_t>(), keys_out.template as<uint32_t>(),
+                                      iota.template as<uint32_t>(), perm.template as<uint32_t>(), (size_t)nnz, 0u, (unsigned)bits, st()));
+      E_HIP(tmp.ensure(bytes));
+      E_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, X.cols.template as<uint32_t>(), keys_out.template as<uint32_t>(),
+                                      iota.template as<uint32_t>(), perm.template as<uint32_t>(), (size_t)nnz, 0u, (unsigned)bits, st()));
+    }
+    lower_bound_ptr_kernel<<<(unsigned)cdiv(V + 1, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), nnz, V,
+                                                                       d_trp.template as<int64_t>());
+    E_LAUNCH();
+    gather_transposed_kernel<T><<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(
+        perm.template as<uint32_t>(), rowid.template as<uint32_t>(), X.vals.template as<T>(), nnz, Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>());
+    E_LAUNCH();
+    set_end_flags_kernel<<<(unsigned)cdiv(m, TB), TB, 0, st()>>>(d_rp.template as<int64_t>(), m, X.cols.template as<uint32_t>(), kLongRow);
+    E_LAUNCH();
+    set_end_flags_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(d_trp.template as<int64_t>(), V, Xt.cols.template as<uint32_t>(), kLongRow);
+    E_LAUNCH();
+    E_HIP(hipMemcpyAsync(Xt.h_rowptr.data(), d_trp.p, (V + 1) * 8, hipMemcpyDeviceToHost, st()));
+    E_HIP(hipStreamSynchronize(st()));
+    have_matrix = true;
+    return 0;
+  }
+
+  int upload(DevBuf& b, const void* src, size_t bytes) {
+    E_HIP(b.ensure(std::max<size_t>(bytes, 16)));
+    if (bytes) E_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st()));
+    return 0;
+  }
+
+  int ensure_segments(StreamMat<T>& M, int64_t q) {
+    if (M.seg_q == q) return 0;
+    HostSegments s;
+    build_segments_host(M.h_rowptr.data(), M.rows, q, kLongRow, s);
+    M.n_seg = s.n_seg();
+    M.n_nzrow = (int64_t)s.nzrow.size();
+    M.n_empty = (int64_t)s.empty_rows.size();
+    M.n_fix = (int64_t)s.fix_row.size();
+    M.n_carry = s.n_carry;
+    MNMF_TRY(upload(M.seg_start, s.seg_start.data(), s.seg_start.size() * 8));
+    MNMF_TRY(upload(M.seg_info, s.seg_info.data(), s.seg_info.size() * 4));
+    MNMF_TRY(upload(M.nzrow, s.nzrow.data(), s.nzrow.size() * 4));
+    MNMF_TRY(upload(M.empty_rows, s.empty_rows.data(), s.empty_rows.size() * 4));
+    MNMF_TRY(upload(M.fix_row, s.fix_row.data(), s.fix_row.size() * 4));
+    MNMF_TRY(upload(M.fix_first, s.fix_first.data(), s.fix_first.size() * 4));
+    MNMF_TRY(upload(M.fix_count, s.fix_count.data(), s.fix_count.size() * 4));
+    E_HIP(hipStreamSynchronize(st()));  // host vectors die at scope exit
+    M.seg_q = q;
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ kernels
+  template <int LPR, int VPL, int U>
+  int spmm_launch(StreamMat<T>& M, const T* B, int ld, T* out) {
+    constexpr int NG = kWave / LPR;
+    const int64_t waves = cdiv(M.n_seg, NG);
+    if (waves > 0) {
+      spmm_stream_kernel<T, LPR, VPL, U><<<(unsigned)cdiv(waves, 4), 256, 0, st()>>>(
+          M.seg_start.template as<int64_t>(), M.seg_info.template as<int32_t>(), M.n_seg, M.cols.template as<uint32_t>(), M.vals.template as<T>(),
+          M.nzrow.template as<int32_t>(), B, ld, out, M.carry.template as<T>());
+      E_LAUNCH();
+    }
+    if (M.n_fix > 0) {
+      spmm_fixup_kernel<T, LPR, VPL><<<(unsigned)cdiv(M.n_fix, 4), 256, 0, st()>>>(
+          M.fix_row.template as<int32_t>(), M.fix_first.template as<int32_t>(), M.fix_count.template as<int32_t>(), M.n_fix, M.carry.template as<T>(),
+          ld, out);
+      E_LAUNCH();
+    }
+    return 0;
+  }
+
+  // out (M.rows x ld) = M . B   (B: M.tab_rows x ld)
+  int spmm(StreamMat<T>& M, const T* B, int ld, T* out) {
+    constexpr int VEC = VecOf<T>::N;
+    const int nvec = ld / VEC;
+    if (ld % VEC != 0 || nvec > 128) return fail(MNMF_EINVAL, "spmm: unsupported k (max 512 f32 / 256 f64)");
+    const int vpl = nvec > 64 ? 2 : 1;
+    const int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
+    const int ng = kWave / lpr;
+    int64_t q = 512;
+    while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
+    MNMF_TRY(ensure_segments(M, q));
+    if (M.n_carry > 0) E_HIP(M.carry.ensure((size_t)M.n_carry * ld * sizeof(T)));
+    if (M.n_empty > 0) {
+      zero_rows_kernel<T><<<(unsigned)cdiv(M.n_empty * ld, 256), 256, 0, st()>>>(M.empty_rows.template as<int32_t>(), M.n_empty,
+                                                                                ld, out);
+      E_LAUNCH();
+    }
+    if (vpl == 2) return spmm_launch<64, 2, 4>(M, B, ld, out);
+    switch (lpr) {
+      case 4: return spmm_launch<4, 1, 4>(M, B, ld, out);
+      case 8: return spmm_launch<8, 1, 8>(M, B, ld, out);
+      case 16: return spmm_launch<16, 1, 8>(M, B, ld, out);
+      case 32: return spmm_launch<32, 1, 8>(M, B, ld, out);
+      default: return spmm_launch<64, 1, 8>(M, B, ld, out);
+    }
+  }
+
+  // out (ld x ld) = A^T B over rows;  diff: operands |A - A2|, |B - B2|
+  int gram(const T* A, const T* A2, const T* B, const T* B2, int64_t rows, int ld, bool diff, T* out) {
+    const int64_t elems = (int64_t)ld * ld;
+    if (rows <= 0) {
+      E_HIP(hipMemsetAsync(out, 0, elems * sizeof(T), st()));
+      return 0;
+    }
+    const int64_t rpc = std::max<int64_t>(256, round_up(cdiv(rows, 1024), 16));
+    const int64_t chunks = cdiv(rows, rpc);
+    E_HIP(slab.ensure((size_t)chunks * elems * sizeof(T)));
+    const int tiles = (ld + 63) / 64;
+    dim3 grid((unsigned)chunks, (unsigned)(tiles * tiles));
+    if (diff)
+      gram_partial_kernel<T, true><<<grid, 256, 0, st()>>>(A, A2, B, B2, rows, ld, rpc, slab.template as<T>());
+    else
+      gram_partial_kernel<T, false><<<grid, 256, 0, st()>>>(A, A2, B, B2, rows, ld, rpc, slab.template as<T>());
+    E_LAUNCH();
+    slab_reduce_kernel<T><<<(unsigned)cdiv(elems, 256), 256, 0, st()>>>(slab.template as<T>(), chunks, elems, out);
+    E_LAUNCH();
+    return 0;
+  }
+
+  int rk(int mode, const T* A1, const T* G1, const T* A2, const T* G2, const T* upd, const T* num, T* out,
+         int64_t rows, int ld, double eps) {
+    if (rows <= 0) return 0;
+    RkArgs<T> a{A1, G1, A2, G2, upd, num, out, rows, ld, (T)eps};
+    dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(ld, 64));
+    if (mode == RK_PROD) dense_rk_kernel<T, RK_PROD><<<grid, 256, 0, st()>>>(a);
+    else if (mode == RK_MU) dense_rk_kernel<T, RK_MU><<<grid, 256, 0, st()>>>(a);
+    else dense_rk_kernel<T, RK_MU_SQRT><<<grid, 256, 0, st()>>>(a);
+    E_LAUNCH();
+    return 0;
+  }
+
+  int kxk(const T* A, const T* B, T* C, int ld, int ta, int tb) {
+    kxk_gemm_kernel<T><<<(unsigned)cdiv((int64_t)ld * ld, 256), 256, 0, st()>>>(A, B, C, ld, ta, tb);
+    E_LAUNCH();
+    return 0;
+  }
+
+  int allreduce(T* p, int64_t count) {
+    if (!ctx->ar) return 0;
+    const int r = ctx->ar(ctx->ar_user, p, count, ctx->dtype, (void*)st());
+    if (r != 0) return fail(MNMF_ECOMM, "all-reduce hook failed with code " + std::to_string(r));
+    return 0;
+  }
+
+  // lambda_max / trace of device Gram(s) -> host.  grams: n matrices of ld x ld, contiguous.
+  int fetch_grams(const T* d, int n, int ld, std::vector<double>& out) {
+    const size_t cnt = (size_t)n * ld * ld;
+    MNMF_TRY(pinned(cnt * (sizeof(T) == 8 ? 1 : 1)));
+    E_HIP(hipMemcpyAsync(h_pinned, d, cnt * sizeof(T), hipMemcpyDeviceToHost, st()));
+    E_HIP(hipStreamSynchronize(st()));
+    out.resize(cnt);
+    const T* hp = reinterpret_cast<const T*>(h_pinned);
+    for (size_t i = 0; i < cnt; ++i) out[i] = (double)hp[i];
+    return 0;
+  }
+  static double spectral_from_gram(const double* g, int ld) { return std::sqrt(std::max(0.0, nonneg_lambda_max(g, ld))); }
+  static double fro_from_gram(const double* g, int ld) {
+    double t = 0.0;
+    for (int i = 0; i < ld; ++i) t += g[(size_t)i * ld + i];
+    return std::sqrt(std::max(0.0, t));
+  }
+
+  int load_W(const void* W, int k, int ld, T* dst) {
+    pad_rows_kernel<T><<<(unsigned)cdiv(std::max<int64_t>(m * ld, 1), 256), 256, 0, st()>>>((const T*)W, m, k, ld, dst);
+    E_LAUNCH();
+    return 0;
+  }
+  int load_H(const void* H, int k, int ld, T* dst) {
+    dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(ld, 32));
+    transpose_in_kernel<T><<<grid, 256, 0, st()>>>((const T*)H, k, V, ld, dst);
+    E_LAUNCH();
+    return 0;
+  }
+  int store_W(const T* src, int k, int ld, double thr, void* W) {
+    if (m * k == 0) return 0;
+    unpad_rows_kernel<T><<<(unsigned)cdiv(m * k, 256), 256, 0, st()>>>(src, m, k, ld, (T)thr, (T*)W);
+    E_LAUNCH();
+    return 0;
+  }
+  int store_H(const T* src, int k, int ld, double thr, void* H) {
+    dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(ld, 32));
+    transpose_out_kernel<T><<<grid, 256, 0, st()>>>(src, k, V, ld, (T)thr, (T*)H);
+    E_LAUNCH();
+    return 0;
+  }
+
+  int check_ready(int k) {
+    if (!have_matrix) return fail(MNMF_ESTATE, "no matrix: call mnmf_set_matrix first");
+    if (k <= 0) return fail(MNMF_EINVAL, "k must be positive");
+    E_HIP(hipSetDevice(ctx->device));
+    return 0;
+  }
+
+  struct LoopClock {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::chrono::steady_clock::time_point t0;
+  };
+  int clock_start(LoopClock& c) {
+    E_HIP(hipEventCreate(&c.e0));
+    E_HIP(hipEventCreate(&c.e1));
+    E_HIP(hipStreamSynchronize(st()));
+    c.t0 = std::chrono::steady_clock::now();
+    E_HIP(hipEventRecord(c.e0, st()));
+    return 0;
+  }
+  int clock_stop(LoopClock& c, mnmf_stats* s) {
+    E_HIP(hipEventRecord(c.e1, st()));
+    E_HIP(hipStreamSynchronize(st()));
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.e0, c.e1);
+    if (s) {
+      s->ms_total = std::chrono::duration<double, std::milli>(t1 - c.t0).count();
+      s->ms_kernels = ms;
+    }
+    (void)hipEventDestroy(c.e0);
+    (void)hipEventDestroy(c.e1);
+    return 0;
+  }
+
+  void model(mnmf_stats* s, int k, double xw, double ww, double hw, double f_nnz, double f_m, double f_v) {
+    if (!s) return;
+    const double sv = sizeof(T), p = std::max(1, ctx->n_ranks);
+    const double Xb = (double)nnz * (sv + 4) + (double)(m + 1) * 8, Wbt = (double)m * k * sv, Hbt = (double)k * V * sv;
+    (void)p;
+    s->bytes_model = xw * Xb + ww * Wbt + hw * Hbt;
+    s->flops_model = f_nnz * (double)nnz * k + f_m * (double)m * k * k + f_v * (double)V * k * k;
+  }
+
+  // ------------------------------------------------------------------ loop A
+  int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
+    MNMF_TRY(check_ready(k));
+    const int ld = ld_of(k);
+    const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 10000;
+    const int fixed = o ? o->fixed_iters : 0;
+    const int every = (o && o->check_every > 0) ? o->check_every : 1;
+    const bool force_check = o && o->force_check;
+    const double thr = (o && o->norm_thresh >= 0) ? o->norm_thresh : 0.005;
+    const double eps = (o && o->eps >= 0) ? o->eps : 1e-10;
+    const double zthr = (o && o->zero_threshold >= 0) ? o->zero_threshold : 1e-5;
+    const bool finalize = !o || o->finalize;
+    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)V * ld * sizeof(T);
+    const size_t gsz = (size_t)ld * ld * sizeof(T);
+    for (int i = 0; i < 2; ++i) {
+      E_HIP(Wb[i].ensure(wsz));
+      E_HIP(Hb[i].ensure(hsz));
+    }
+    E_HIP(Nw.ensure(wsz));
+    E_HIP(Ex.ensure(hsz + gsz));       // [Nh (V x ld) | WtW (ld x ld)]: one all-reduce
+    E_HIP(small.ensure(4 * gsz));      // HHt, dW gram, dH gram
+    T* Nh = Ex.template as<T>();
+    T* Gw = Nh + (size_t)V * ld;
+    T* Gh = small.template as<T>();
+    T* Gd = Gh + (size_t)ld * ld;      // [dW gram | dH gram] contiguous
+    MNMF_TRY(load_W(W, k, ld, Wb[0].template as<T>()));
+    MNMF_TRY(load_H(H, k, ld, Hb[0].template as<T>()));
+    int cw = 0, ch = 0;
+    double w_norm = INFINITY, h_norm = INFINITY;
+    int64_t i = 0;
+    int converged = 0;
+    LoopClock clk;
+    MNMF_TRY(clock_start(clk));
+    PhaseTimer pt(st(), o && o->profile_phases);
+    pt.mark(-1);
+    std::vector<double> g;
+    while (true) {
+      T* Wc = Wb[cw].template as<T>();
+      T* Wn = Wb[1 - cw].template as<T>();
+      T* Hc = Hb[ch].template as<T>();
+      T* Hn = Hb[1 - ch].template as<T>();
+      MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gw));      // wT_w                nmf_basic.py:39
+      pt.mark(0);
+      MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
+      pt.mark(1);
+      MNMF_TRY(allreduce(Nh, (int64_t)V * ld + (int64_t)ld * ld));
+      MNMF_TRY(rk(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps));  // h update       :41-42
+      pt.mark(2);
+      MNMF_TRY(gram(Hn, nullptr, Hn, nullptr, V, ld, false, Gh));      // h_hT (new h)         :44
+      pt.mark(3);
+      MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                            // in_mat @ h.T         :45
+      pt.mark(4);
+      MNMF_TRY(rk(RK_MU, Wc, Gh, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps));  // w update :46-47
+      pt.mark(5);
+      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+      if (do_check) {
+        MNMF_TRY(gram(Wn, Wc, Wn, Wc, m, ld, true, Gd));                // D^T D, D = |w - w_old|   :52
+        MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
+        MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + (size_t)ld * ld));  // :53
+        MNMF_TRY(fetch_grams(Gd, 2, ld, g));
+        w_norm = spectral_from_gram(g.data(), ld);
+        h_norm = spectral_from_gram(g.data() + (size_t)ld * ld, ld);
+        pt.mark(6);
+        if (!std::isfinite(w_norm) || !std::isfinite(h_norm)) {
+          cw = 1 - cw;
+          ch = 1 - ch;
+          ++i;
+          (void)clock_stop(clk, stats);
+          return fail(MNMF_ENAN, "nmf: non-finite update norm at iteration " + std::to_string(i));
+        }
+      }
+      cw = 1 - cw;
+      ch = 1 - ch;
+      if (fixed > 0) {
+        if (i + 1 >= fixed) break;
+      } else {
+        if (i >= max_iter) break;                                      // :57
+        if (do_check && w_norm < thr && h_norm < thr) {                // :62
+          converged = 1;
+          break;
+        }
+      }
+      ++i;
+    }
+    MNMF_TRY(clock_stop(clk, stats));
+    pt.collect(phase_ms);
+    if (stats) std::memcpy(stats->phase_ms, phase_ms, sizeof(phase_ms));
+    MNMF_TRY(store_W(Wb[cw].template as<T>(), k, ld, finalize ? zthr : -1.0, W));  // :86
+    MNMF_TRY(store_H(Hb[ch].template as<T>(), k, ld, finalize ? zthr : -1.0, H));  // :87
+    E_HIP(hipStreamSynchronize(st()));
+    if (stats) {
+      stats->iters = (int32_t)(i + 1);
+      stats->converged = converged;
+      stats->w_norm = w_norm;
+      stats->h_norm = h_norm;
+      stats->s_norm = 0;
+      model(stats, k, 2, 3, 6, 4, 4, 4);
+    }
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ loop B
+  int run_pnmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
+    MNMF_TRY(check_ready(k));
+    const int ld = ld_of(k);
+    const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 1000;
+    const int fixed = o ? o->fixed_iters : 0;
+    const int every = (o && o->check_every > 0) ? o->check_every : 1;
+    const bool force_check = o && o->force_check;
+    const double delta = (o && o->norm_thresh >= 0) ? o->norm_thresh : 0.005;
+    const double eps = (o && o->eps >= 0) ? o->eps : 1e-10;
+    const double zthr = (o && o->zero_threshold >= 0) ? o->zero_threshold : 1e-10;
+    const bool finalize = !o || o->finalize;
+    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)V * ld * sizeof(T);
+    const size_t gsz = (size_t)ld * ld * sizeof(T);
+    for (int i = 0; i < 2; ++i) E_HIP(Wb[i].ensure(wsz));
+    E_HIP(Nw.ensure(wsz));         // pay
+    E_HIP(Ex.ensure(hsz + gsz));   // [vtw (V x ld) | wtw]
+    E_HIP(small.ensure(4 * gsz));  // wt_pay, dW gram, colnorm gram, norms
+    T* vtw = Ex.template as<T>();
+    T* wtw = vtw + (size_t)V * ld;
+    T* wt_pay = small.template as<T>();
+    T* Gd = wt_pay + (size_t)ld * ld;
+    T* Gn = Gd + (size_t)ld * ld;
+    T* nrm = Gn + (size_t)ld * ld;
+    T* pay = Nw.template as<T>();
+    MNMF_TRY(load_W(W, k, ld, Wb[0].template as<T>()));
+    int cw = 0;
+    double w_norm = INFINITY;
+    int64_t i = 0;
+    int converged = 0;
+    const int64_t limit = fixed > 0 ? fixed : max_iter;
+    LoopClock clk;
+    MNMF_TRY(clock_start(clk));
+    PhaseTimer pt(st(), o && o->profile_phases);
+    pt.mark(-1);
+    std::vector<double> g;
+    while (i < limit) {                                                  // nmf_projective_basic.py:61
+      T* Wc = Wb[cw].template as<T>();
+      T* Wn = Wb[1 - cw].template as<T>();
+      MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, wtw));      // wtw = W.T @ W       :68
+      pt.mark(0);
+      MNMF_TRY(spmm(Xt, Wc, ld, vtw));                                   // vtw = X.T @ W       :69
+      pt.mark(1);
+      MNMF_TRY(allreduce(vtw, (int64_t)V * ld + (int64_t)ld * ld));
+      MNMF_TRY(spmm(X, vtw, ld, pay));                                   // pay = X @ vtw       :72
+      pt.mark(4);
+      MNMF_TRY(gram(Wc, nullptr, pay, nullptr, m, ld, false, wt_pay));  // wt_pay = W.T @ pay  :75
+      MNMF_TRY(allreduce(wt_pay, (int64_t)ld * ld));
+      pt.mark(3);
+      // payda = W @ wt_pay + pay @ wtw + eps ; w_new = W * sqrt(pay / payda)                  :76-79
+      MNMF_TRY(rk(RK_MU_SQRT, Wc, wt_pay, pay, wtw, Wc, pay, Wn, m, ld, eps));
+      pt.mark(5);
+      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+      if (do_check) {
+        MNMF_TRY(gram(Wn, Wc, Wn, Wc, m, ld, true, Gd));                 // :83
+        MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
+        MNMF_TRY(fetch_grams(Gd, 1, ld, g));
+        w_norm = spectral_from_gram(g.data(), ld);
+        pt.mark(6);
+        if (!std::isfinite(w_norm)) {
+          (void)clock_stop(clk, stats);
+          return fail(MNMF_ENAN, "pnmf: non-finite update norm at iteration " + std::to_string(i + 1));
+        }
+        if (fixed <= 0 && w_norm < delta) {                              // break BEFORE W = w_new   :101-107
+          converged = 1;
+          break;
+        }
+      }
+      cw = 1 - cw;
+      ++i;
+    }
+    MNMF_TRY(clock_stop(clk, stats));
+    pt.collect(phase_ms);
+    if (stats) std::memcpy(stats->phase_ms, phase_ms, sizeof(phase_ms));
+    T* Wc = Wb[cw].template as<T>();
+    if (finalize) {
+      threshold_kernel<T><<<(unsigned)cdiv(std::max<int64_t>(m * ld, 1), 256), 256, 0, st()>>>(Wc, m * ld, (T)zthr);  // :111
+      E_LAUNCH();
+      MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gn));        // column sums of squares = diag
+      MNMF_TRY(allreduce(Gn, (int64_t)ld * ld));
+      const T tiny = (T)(10.0 * (sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920929e-07));
+      inv_colnorm_kernel<T><<<(unsigned)cdiv(ld, 256), 256, 0, st()>>>(Gn, ld, tiny, nrm);
+      E_LAUNCH();
+      if (m > 0) {
+        div_cols_kernel<T><<<(unsigned)cdiv(m * ld, 256), 256, 0, st()>>>(Wc, m, ld, nrm);  // normalize(W, 'l2', axis=0) :114
+        E_LAUNCH();
+      }
+    }
+    MNMF_TRY(spmm(Xt, Wc, ld, vtw));                                      // h = w.T @ X         :115
+    MNMF_TRY(allreduce(vtw, (int64_t)V * ld));
+    MNMF_TRY(store_W(Wc, k, ld, -1.0, W));
+    MNMF_TRY(store_H(vtw, k, ld, -1.0, H));
+    E_HIP(hipStreamSynchronize(st()));
+    if (stats) {
+      stats->iters = (int32_t)i;
+      stats->converged = converged;
+      stats->w_norm = w_norm;
+      stats->h_norm = 0;
+      stats->s_norm = 0;
+      model(stats, k, 2, 6, 3, 4, 8, 0);
+    }
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ loop C
+  int run_nmtf(int k, void* W, void* S, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
+    MNMF_TRY(check_ready(k));
+    const int ld = ld_of(k);
+    const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 1000;
+    const int fixed = o ? o->fixed_iters : 0;
+    const int every = (o && o->check_every > 0) ? o->check_every : 1;
+    const bool force_check = o && o->force_check;
+    const double thr = (o && o->norm_thresh >= 0) ? o->norm_thresh : 0.005;
+    const double eps = (o && o->eps >= 0) ? o->eps : 1e-9;
+    const double zthr = (o && o->zero_threshold >= 0) ? o->zero_threshold : 1e-5;
+    const bool finalize = !o || o->finalize;
+    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)V * ld * sizeof(T);
+    const size_t gel = (size_t)ld * ld, gsz = gel * sizeof(T);
+    for (int i = 0; i < 2; ++i) {
+      E_HIP(Wb[i].ensure(wsz));
+      E_HIP(Hb[i].ensure(hsz));
+    }
+    E_HIP(Nw.ensure(wsz));
+    E_HIP(Ex.ensure(hsz + gsz));     // [Pt (V x ld) | w1T w1]
+    E_HIP(Aux1.ensure(hsz));         // M1 = hT sT, later M2 = Pt s1
+    E_HIP(small.ensure(16 * gsz));
+    T* Pt = Ex.template as<T>();
+    T* Gw1 = Pt + (size_t)V * ld;
+    T* M1 = Aux1.template as<T>();
+    T* sm = small.template as<T>();
+    T* Sb[2] = {sm, sm + gel};
+    T* ST = sm + 2 * gel;
+    T* hhT = sm + 3 * gel;
+    T* T1 = sm + 4 * gel;
+    T* Dm = sm + 5 * gel;
+    T* num_s = sm + 6 * gel;
+    T* T2 = sm + 7 * gel;
+    T* den_s = sm + 8 * gel;
+    T* T3 = sm + 9 * gel;
+    T* Qm = sm + 10 * gel;
+    T* Gd = sm + 11 * gel;  // [dW gram | dH gram]
+    // S in: k x k -> ld x ld padded
+    pad_sq(S, k, ld, Sb[0]);
+    E_LAUNCH();
+    MNMF_TRY(load_W(W, k, ld, Wb[0].template as<T>()));
+    MNMF_TRY(load_H(H, k, ld, Hb[0].template as<T>()));
+    int cw = 0, ch = 0, cs = 0;
+    double w_norm = INFINITY, h_norm = INFINITY, s_norm = INFINITY;
+    int64_t i = 0;
+    int converged = 0;
+    LoopClock clk;
+    MNMF_TRY(clock_start(clk));
+    PhaseTimer pt(st(), o && o->profile_phases);
+    pt.mark(-1);
+    std::vector<double> g, sh;
+    const unsigned kb = (unsigned)cdiv((int64_t)gel, 256);
+    while (true) {
+      T* Wc = Wb[cw].template as<T>();
+      T* Wn = Wb[1 - cw].template as<T>();
+      T* Hc = Hb[ch].template as<T>();
+      T* Hn = Hb[1 - ch].template as<T>();
+      T* Sc = Sb[cs];
+      T* Sn = Sb[1 - cs];
+      // ---- W update                                                   nmtf.py:151-153
+      kxk_transpose_kernel<T><<<kb, 256, 0, st()>>>(Sc, ST, ld);
+      E_LAUNCH();
+      MNMF_TRY(rk(RK_PROD, Hc, ST, nullptr, nullptr, nullptr, nullptr, M1, V, ld, 0));  // h.T @ s.T
+      pt.mark(2);
+      MNMF_TRY(spmm(X, M1, ld, Nw.template as<T>()));                             // in_mat @ (h.T @ s.T)
+      pt.mark(4);
+      MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));      // h @ h.T
+      pt.mark(3);
+      MNMF_TRY(kxk(Sc, hhT, T1, ld, 0, 0));                              // s (h hT)
+      MNMF_TRY(kxk(T1, Sc, Dm, ld, 0, 1));                               // s (h hT) sT
+      MNMF_TRY(rk(RK_MU, Wc, Dm, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps));
+      pt.mark(5);
+      // ---- S update                                                   nmtf.py:156-158
+      MNMF_TRY(gram(Wn, nullptr, Wn, nullptr, m, ld, false, Gw1));      // w1.T @ w1
+      pt.mark(0);
+      MNMF_TRY(spmm(Xt, Wn, ld, Pt));                                    // (w1.T @ in_mat)^T
+      pt.mark(1);
+      MNMF_TRY(allreduce(Pt, (int64_t)V * ld + (int64_t)gel));
+      MNMF_TRY(gram(Pt, nullptr, Hc, nullptr, V, ld, false, num_s));    // (w1.T X) @ h.T
+      MNMF_TRY(kxk(Gw1, Sc, T2, ld, 0, 0));
+      MNMF_TRY(kxk(T2, hhT, den_s, ld, 0, 0));                           // (w1T w1) s (h hT)
+      kxk_mu_kernel<T><<<kb, 256, 0, st()>>>(Sc, num_s, den_s, (T)eps, Sn, ld);
+      E_LAUNCH();
+      pt.mark(3);
+      // ---- H update                                                   nmtf.py:161-163
+      MNMF_TRY(rk(RK_PROD, Pt, Sn, nullptr, nullptr, nullptr, nullptr, M1, V, ld, 0));  // (s1.T @ P)^T = Pt s1
+      MNMF_TRY(kxk(Sn, Gw1, T3, ld, 1, 0));                              // s1T (w1T w1)
+      MNMF_TRY(kxk(T3, Sn, Qm, ld, 0, 0));                               // s1T (w1T w1) s1   (symmetric)
+      MNMF_TRY(rk(RK_MU, Hc, Qm, nullptr, nullptr, Hc, M1, Hn, V, ld, eps));
+      pt.mark(2);
+      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+      if (do_check) {                                                     // Frobenius norms   nmtf.py:179-181
+        MNMF_TRY(gram(Wn, Wc, Wn, Wc, m, ld, true, Gd));
+        MNMF_TRY(allreduce(Gd, (int64_t)gel));
+        MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + gel));
+        MNMF_TRY(fetch_grams(Gd, 2, ld, g));
+        w_norm = fro_from_gram(g.data(), ld);
+        h_norm = fro_from_gram(g.data() + gel, ld);
+        MNMF_TRY(fetch_grams(Sb[0], 2, ld, sh));
+        double acc = 0;
+        for (size_t e = 0; e < gel; ++e) {
+          const double d = sh[e] - sh[gel + e];
+          acc += d * d;
+        }
+        s_norm = std::sqrt(acc);
+        pt.mark(6);
+        if (!std::isfinite(w_norm) || !std::isfinite(h_norm) || !std::isfinite(s_norm)) {
+          (void)clock_stop(clk, stats);
+          return fail(MNMF_ENAN, "nmtf: non-finite update norm at iteration " + std::to_string(i + 1));
+        }
+      }
+      cw = 1 - cw;
+      ch = 1 - ch;
+      cs = 1 - cs;
+      ++i;                                                                // :197
+      if (fixed > 0) {
+        if (i >= fixed) break;
+      } else {
+        if (do_check && w_norm < thr && h_norm < thr && s_norm < thr) {   // :200
+          converged = 1;
+          break;
+        }
+        if (i > max_iter) break;                                          // :204
+      }
+    }
+    MNMF_TRY(clock_stop(clk, stats));
+    pt.collect(phase_ms);
+    if (stats) std::memcpy(stats->phase_ms, phase_ms, sizeof(phase_ms));
+    MNMF_TRY(store_W(Wb[cw].template as<T>(), k, ld, finalize ? zthr : -1.0, W));   // :210-212
+    MNMF_TRY(store_H(Hb[ch].template as<T>(), k, ld, finalize ? zthr : -1.0, H));
+    unpad_sq(Sb[cs], k, ld, finalize ? zthr : -1.0, S);
+    E_LAUNCH();
+    E_HIP(hipStreamSynchronize(st()));
+    if (stats) {
+      stats->iters = (int32_t)i;
+      stats->converged = converged;
+      stats->w_norm = w_norm;
+      stats->h_norm = h_norm;
+      stats->s_norm = s_norm;
+      model(stats, k, 2, 5, 9, 4, 6, 10);
+    }
+    return 0;
+  }
+
+  void pad_sq(const void* S, int k, int ld, T* dst) {
+    pad_sq_kernel<T><<<(unsigned)cdiv((int64_t)ld * ld, 256), 256, 0, st()>>>((const T*)S, k, ld, dst);
+  }
+  void unpad_sq(const T* src, int k, int ld, double thr, void* S) {
+    unpad_rows_kernel<T><<<(unsigned)cdiv((int64_t)k * k, 256), 256, 0, st()>>>(src, k, k, ld, (T)thr, (T*)S);
+  }
+
+  // ------------------------------------------------------------------ kernel-level entry points
+  int k_spmm(int transpose, int k, const void* B, void* out) override {
+    MNMF_TRY(check_ready(k));
+    const int ld = ld_of(k);
+    StreamMat<T>& M = transpose ? Xt : X;
+    E_HIP(tmpA.ensure((size_t)std::max<int64_t>(M.tab_rows, 1) * ld * sizeof(T)));
+    E_HIP(tmpB.ensure((size_t)std::max<int64_t>(M.rows, 1) * ld * sizeof(T)));
+    pad_rows_kernel<T><<<(unsigned)cdiv(std::max<int64_t>(M.tab_rows * ld, 1), 256), 256, 0, st()>>>((const T*)B, M.tab_rows, k, ld, tmpA.template as<T>());
+    E_LAUNCH();
+    MNMF_TRY(spmm(M, tmpA.template as<T>(), ld, tmpB.template as<T>()));
+    if (M.rows * k > 0) {
+      unpad_rows_kernel<T><<<(unsigned)cdiv(M.rows * k, 256), 256, 0, st()>>>(tmpB.template as<T>(), M.rows, k, ld, (T)-1, (T*)out);
+      E_LAUNCH();
+    }
+    E_HIP(hipStreamSynchronize(st()));
+    return 0;
+  }
+
+  int pad_into(DevBuf& b, const void* src, int64_t rows, int k, int ld) {
+    E_HIP(b.ensure((size_t)std::max<int64_t>(rows, 1) * ld * sizeof(T)));
+    pad_rows_kernel<T><<<(unsigned)cdiv(std::max<int64_t>(rows * ld, 1), 256), 256, 0, st()>>>((const T*)src, rows, k, ld, b.template as<T>());
+    E_LAUNCH();
+    return 0;
+  }
+
+  int k_gram(int64_t rows, int k, const void* A, const void* B, void* out) override {
+    if (k <= 0 || rows < 0) return fail(MNMF_EINVAL, "gram: bad shape");
+    E_HIP(hipSetDevice(ctx->device));
+    const int ld = ld_of(k);
+    MNMF_TRY(pad_into(tmpA, A, rows, k, ld));
+    if (B) MNMF_TRY(pad_into(tmpB, B, rows, k, ld));
+    E_HIP(tmpC.ensure((size_t)ld * ld * sizeof(T)));
+    MNMF_TRY(gram(tmpA.template as<T>(), nullptr, B ? tmpB.template as<T>() : tmpA.template as<T>(), nullptr, rows, ld, false, tmpC.template as<T>()));
+    unpad_sq(tmpC.template as<T>(), k, ld, -1.0, out);
+    E_LAUNCH();
+    E_HIP(hipStreamSynchronize(st()));
+    return 0;
+  }
+
+  int k_update(int64_t rows, int k, const void* A, const void* num, const void* G, const void* G2, double eps,
+               int sqrt_mode, void* out) override {
+    if (k <= 0 || rows < 0) return fail(MNMF_EINVAL, "update: bad shape");
+    E_HIP(hipSetDevice(ctx->device));
+    const int ld = ld_of(k);
+    const size_t gel = (size_t)ld * ld;
+    MNMF_TRY(pad_into(tmpA, A, rows, k, ld));
+    MNMF_TRY(pad_into(tmpB, num, rows, k, ld));
+    E_HIP(tmpC.ensure(2 * gel * sizeof(T)));
+    E_HIP(tmpD.ensure((size_t)std::max<int64_t>(rows, 1) * ld * sizeof(T)));
+    pad_sq(G, k, ld, tmpC.template as<T>());
+    E_LAUNCH();
+    if (sqrt_mode) {
+      if (!G2) return fail(MNMF_EINVAL, "update: sqrt_mode needs G2");
+      pad_sq(G2, k, ld, tmpC.template as<T>() + gel);
+      E_LAUNCH();
+      MNMF_TRY(rk(RK_MU_SQRT, tmpA.template as<T>(), tmpC.template as<T>(), tmpB.template as<T>(), tmpC.template as<T>() + gel, tmpA.template as<T>(), tmpB.template as<T>(),
+                  tmpD.template as<T>(), rows, ld, eps));
+    } else {
+      MNMF_TRY(rk(RK_MU, tmpA.template as<T>(), tmpC.template as<T>(), nullptr, nullptr, tmpA.template as<T>(), tmpB.template as<T>(), tmpD.template as<T>(), rows,
+                  ld, eps));
+    }
+    if (rows * k > 0) {
+      unpad_rows_kernel<T><<<(unsigned)cdiv(rows * k, 256), 256, 0, st()>>>(tmpD.template as<T>(), rows, k, ld, (T)-1, (T*)out);
+      E_LAUNCH();
+    }
+    E_HIP(hipStreamSynchronize(st()));
+    return 0;
+  }
+
+  int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) override {
+    if (k <= 0 || rows < 0 || !out) return fail(MNMF_EINVAL, "diff_norm: bad arguments");
+    E_HIP(hipSetDevice(ctx->device));
+    const int ld = ld_of(k);
+    MNMF_TRY(pad_into(tmpA, A, rows, k, ld));
+    MNMF_TRY(pad_into(tmpB, B, rows, k, ld));
+    E_HIP(tmpC.ensure((size_t)ld * ld * sizeof(T)));
+    MNMF_TRY(gram(tmpA.template as<T>(), tmpB.template as<T>(), tmpA.template as<T>(), tmpB.template as<T>(), rows, ld, true, tmpC.template as<T>()));
+    std::vector<double> g;
+    MNMF_TRY(fetch_grams(tmpC.template as<T>(), 1, ld, g));
+    *out = kind == 0 ? spectral_from_gram(g.data(), ld) : fro_from_gram(g.data(), ld);
+    return 0;
+  }
+};
+
+}  // namespace
+
+// =========================================================================== C-ABI
+extern "C" {
+
+const char* mnmf_version(void) { return "mnmf 0.1 (gfx950)"; }
+
+int mnmf_create(mnmf_ctx** out, int device, int dtype, void* hip_stream) {
+  if (!out || (dtype != MNMF_F32 && dtype != MNMF_F64)) return MNMF_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MNMF_EHIP;
+  if (hipSetDevice(device) != hipSuccess) return MNMF_EHIP;
+  mnmf_ctx* c = new mnmf_ctx();
+  c->device = device;
+  c->dtype = dtype;
+  c->stream = (hipStream_t)hip_stream;
+  if (dtype == MNMF_F32) c->impl = new Engine<float>(c); else c->impl = new Engine<double>(c);
+  *out = c;
+  return MNMF_OK;
+}
+
+void mnmf_destroy(mnmf_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  delete ctx->impl;
+  delete ctx;
+}
+
+const char* mnmf_last_error(const mnmf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ranks) {
+  if (!ctx) return MNMF_EINVAL;
+  ctx->ar = fn;
+  ctx->ar_user = user;
+  ctx->n_ranks = n_ranks > 0 ? n_ranks : 1;
+  return MNMF_OK;
+}
+
+int mnmf_set_matrix(mnmf_ctx* ctx, int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                    const void* vals, int on_device) {
+  if (!ctx) return MNMF_EINVAL;
+  return ctx->impl->set_matrix(m, V, nnz, rowptr, colidx, vals, on_device);
+}
+
+int mnmf_run_nmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
+  if (!ctx || !W || !H) return MNMF_EINVAL;
+  return ctx->impl->run_nmf(k, W, H, opts, stats);
+}
+int mnmf_run_pnmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
+  if (!ctx || !W || !H) return MNMF_EINVAL;
+  return ctx->impl->run_pnmf(k, W, H, opts, stats);
+}
+int mnmf_run_nmtf(mnmf_ctx* ctx, int k, void* W, void* S, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
+  if (!ctx || !W || !S || !H) return MNMF_EINVAL;
+  return ctx->impl->run_nmtf(k, W, S, H, opts, stats);
+}
+int mnmf_spmm(mnmf_ctx* ctx, int transpose, int k, const void* B, void* out) {
+  if (!ctx || !B || !out) return MNMF_EINVAL;
+  return ctx->impl->k_spmm(transpose, k, B, out);
+}
+int mnmf_gram(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, void* out) {
+  if (!ctx || !A || !out) return MNMF_EINVAL;
+  return ctx->impl->k_gram(rows, k, A, B, out);
+}
+int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* num, const void* G, const void* G2,
+                double eps, int sqrt_mode, void* out) {
+  if (!ctx || !A || !num || !G || !out) return MNMF_EINVAL;
+  return ctx->impl->k_update(rows, k, A, num, G, G2, eps, sqrt_mode, out);
+}
+int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind, double* out) {
+  if (!ctx || !A || !B) return MNMF_EINVAL;
+  return ctx->impl->k_diff_norm(rows, k, A, B, norm_kind, out);
+}
+
+int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || !dst || !src || bytes < 0) return MNMF_EINVAL;
+  if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+    ctx->fail(MNMF_EHIP, "mnmf_memcpy_d2d failed");
+    return MNMF_EHIP;
+  }
+  return MNMF_OK;
+}
+
+int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t long_row, mnmf_segments* out) {
+  if (!rowptr || !out || rows < 0) return MNMF_EINVAL;
+  HostSegments s;
+  build_segments_host(rowptr, rows, seg_nnz, long_row, s);
+  auto dup64 = [](const std::vector<int64_t>& v) {
+    int64_t* p = (int64_t*)std::malloc(std::max<size_t>(v.size(), 1) * 8);
+    std::memcpy(p, v.data(), v.size() * 8);
+    return p;
+  };
+  auto dup32 = [](const std::vector<int32_t>& v) {
+    int32_t* p = (int32_t*)std::malloc(std::max<size_t>(v.size(), 1) * 4);
+    std::memcpy(p, v.data(), v.size() * 4);
+    return p;
+  };
+  out->n_seg = s.n_seg();
+  out->seg_start = dup64(s.seg_start);
+  out->seg_info = dup32(s.seg_info);
+  out->n_nzrow = (int64_t)s.nzrow.size();
+  out->nzrow = dup32(s.nzrow);
+  out->n_empty = (int64_t)s.empty_rows.size();
+  out->empty_rows = dup32(s.empty_rows);
+  out->n_fix = (int64_t)s.fix_row.size();
+  out->fix_row = dup32(s.fix_row);
+  out->fix_first = dup32(s.fix_first);
+  out->fix_count = dup32(s.fix_count);
+  out->n_carry = s.n_carry;
+  return MNMF_OK;
+}
+
+void mnmf_free_segments(mnmf_segments* s) {
+  if (!s) return;
+  std::free(s->seg_start);
+  std::free(s->seg_info);
+  std::free(s->nzrow);
+  std::free(s->empty_rows);
+  std::free(s->fix_row);
+  std::free(s->fix_first);
+  std::free(s->fix_count);
+  std::memset(s, 0, sizeof(*s));
+}
+
+double mnmf_sym_lambda_max(const double* a, int n) { return a ? sym_lambda_max_jacobi(a, n) : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+"""Python handle on one mnmf context (one GPU).  torch supplies device memory, the stream and
+torch.distributed; every numeric step runs in libmnmf.so (HIP)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_DTYPE = {"fp32": torch.float32, "fp64": torch.float64}
+_CODE = {"fp32": _lib.MNMF_F32, "fp64": _lib.MNMF_F64}
+PHASES = ("gram_w", "spmm_xt", "h_side", "gram_h_kxk", "spmm_x", "w_update", "check", "unused")
+
+
+class MnmfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_lib.STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+@dataclass
+class Stats:
+    iters: int = 0
+    converged: bool = False
+    w_norm: float = float("inf")
+    h_norm: float = float("inf")
+    s_norm: float = float("inf")
+    ms_total: float = 0.0
+    ms_kernels: float = 0.0
+    bytes_model: float = 0.0
+    flops_model: float = 0.0
+    phase_ms: dict = field(default_factory=dict)
+
+
+def _opts(max_iter=-1, fixed_iters=0, check_every=1, force_check=False, finalize=True, profile=False,
+          norm_thresh=-1.0, eps=-1.0, zero_threshold=-1.0):
+    o = _lib.MnmfOpts()
+    o.max_iter = int(max_iter)
+    o.fixed_iters = int(fixed_iters or 0)
+    o.check_every = int(check_every)
+    o.force_check = int(bool(force_check))
+    o.finalize = int(bool(finalize))
+    o.profile_phases = int(bool(profile))
+    o.norm_thresh = float(norm_thresh)
+    o.eps = float(eps)
+    o.zero_threshold = float(zero_threshold)
+    return o
+
+
+class Engine:
+    """One resident matrix + solver workspaces on one MI355X."""
+
+    def __init__(self, device=None, dtype="fp32"):
+        if dtype not in _CODE:
+            raise ValueError("dtype must be 'fp32' or 'fp64'")
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("manta_amd: no GPU visible (torch.cuda.is_available() is False); "
+                               "the engine has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device) else device.index or 0)
+        self.dtype = dtype
+        self.tdtype = _TORCH_DTYPE[dtype]
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self._lib.mnmf_create(C.byref(h), self.device.index, _CODE[dtype], C.c_void_p(self.stream.cuda_stream))
+        if rc != 0:
+            raise MnmfError(rc, "mnmf_create failed")
+        self._h = h
+        self.m = self.V = self.nnz = 0
+        self._hook = None      # keep the ctypes callback alive
+        self._stage = None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mnmf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MnmfError(rc, self._lib.mnmf_last_error(self._h).decode())
+
+    def _dev(self, a):
+        """numpy / torch -> contiguous device tensor of the engine dtype."""
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=self.tdtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=self.tdtype).contiguous()
+
+    @staticmethod
+    def _host(t):
+        return t.detach().to("cpu", torch.float64).numpy()
+
+    def _stats(self, s):
+        return Stats(iters=s.iters, converged=bool(s.converged), w_norm=s.w_norm, h_norm=s.h_norm, s_norm=s.s_norm,
+                     ms_total=s.ms_total, ms_kernels=s.ms_kernels, bytes_model=s.bytes_model,
+                     flops_model=s.flops_model, phase_ms={n: s.phase_ms[i] for i, n in enumerate(PHASES)})
+
+    # ------------------------------------------------------------------ matrix
+    def set_matrix(self, X=None, *, rowptr=None, colidx=None, vals=None, shape=None):
+        """``X``: a scipy sparse matrix (host), or give device/host tensors ``rowptr`` (int64), ``colidx``
+        (int32), ``vals`` and ``shape``.  The engine copies and keeps X and X^T resident."""
+        if X is not None:
+            X = X.tocsr()
+            X.sort_indices()
+            shape = X.shape
+            rowptr = torch.from_numpy(X.indptr.astype(np.int64))
+            colidx = torch.from_numpy(X.indices.astype(np.int32))
+            vals = torch.from_numpy(np.asarray(X.data))
+        m, V = int(shape[0]), int(shape[1])
+        rowptr = rowptr.to(device=self.device, dtype=torch.int64).contiguous()
+        colidx = colidx.to(device=self.device, dtype=torch.int32).contiguous()
+        vals = vals.to(device=self.device, dtype=self.tdtype).contiguous()
+        nnz = int(colidx.numel())
+        if rowptr.numel() != m + 1 or vals.numel() != nnz:
+            raise ValueError("CSR arrays do not match the shape")
+        self._check(self._lib.mnmf_set_matrix(self._h, m, V, nnz, rowptr.data_ptr(), colidx.data_ptr(),
+                                              vals.data_ptr(), 1))
+        self.m, self.V, self.nnz = m, V, nnz
+
+    # ------------------------------------------------------------------ multi-GPU hook
+    def set_process_group(self, group=None):
+        """Install a sum-all-reduce hook over ``torch.distributed`` (nccl = RCCL over xGMI; with the
+        gloo backend the exchange is staged through the host, for tests)."""
+        import torch.distributed as dist
+
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            self._lib.mnmf_set_allreduce(self._h, C.cast(None, _lib.ALLREDUCE_FN), None, 1)
+            self._hook = None
+            return
+        backend = dist.get_backend(group)
+        eng = self
+
+        def hook(_user, ptr, count, _dtype, _stream):
+            try:
+                if eng._stage is None or eng._stage.numel() < count:
+                    eng._stage = torch.empty(int(count), dtype=eng.tdtype, device=eng.device)
+                buf = eng._stage[:count]
+                nbytes = count * buf.element_size()
+                if eng._lib.mnmf_memcpy_d2d(eng._h, buf.data_ptr(), ptr, nbytes) != 0:
+                    return 1
+                if backend == "nccl":
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                else:
+                    host = buf.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                    buf.copy_(host)
+                if eng._lib.mnmf_memcpy_d2d(eng._h, ptr, buf.data_ptr(), nbytes) != 0:
+                    return 2
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print(f"[manta_amd] all-reduce hook failed: {e!r}", flush=True)
+                return 3
+
+        self._hook = _lib.ALLREDUCE_FN(hook)
+        self._check(self._lib.mnmf_set_allreduce(self._h, self._hook, None, dist.get_world_size(group)))
+
+    # ------------------------------------------------------------------ solvers
+    def run_nmf(self, W0, H0, **kw):
+        W, H = self._dev(W0).clone(), self._dev(H0).clone()
+        k = W.shape[1]
+        if W.shape != (self.m, k) or H.shape != (k, self.V):
+            raise ValueError(f"W0 {tuple(W.shape)} / H0 {tuple(H.shape)} do not match X {self.m}x{self.V}")
+        o, s = _opts(**kw), _lib.MnmfStats()
+        self._check(self._lib.mnmf_run_nmf(self._h, k, W.data_ptr(), H.data_ptr(), C.byref(o), C.byref(s)))
+        return W, H, self._stats(s)
+
+    def run_pnmf(self, W0, **kw):
+        W = self._dev(W0).clone()
+        k = W.shape[1]
+        if W.shape[0] != self.m:
+            raise ValueError("W0 does not match X")
+        H = torch.empty((k, self.V), dtype=self.tdtype, device=self.device)
+        o, s = _opts(**kw), _lib.MnmfStats()
+        self._check(self._lib.mnmf_run_pnmf(self._h, k, W.data_ptr(), H.data_ptr(), C.byref(o), C.byref(s)))
+        return W, H, self._stats(s)
+
+    def run_nmtf(self, W0, S0, H0, **kw):
+        W, S, H = self._dev(W0).clone(), self._dev(S0).clone(), self._dev(H0).clone()
+        k = W.shape[1]
+        if W.shape != (self.m, k) or H.shape != (k, self.V) or S.shape != (k, k):
+            raise ValueError("W0/S0/H0 do not match X")
+        o, s = _opts(**kw), _lib.MnmfStats()
+        self._check(self._lib.mnmf_run_nmtf(self._h, k, W.data_ptr(), S.data_ptr(), H.data_ptr(), C.byref(o), C.byref(s)))
+        return W, S, H, self._stats(s)
+
+    # ------------------------------------------------------------------ kernel-level
+    def spmm(self, B, transpose=False):
+        B = self._dev(B)
+        k = B.shape[1]
+        rows_in, rows_out = (self.m, self.V) if transpose else (self.V, self.m)
+        if B.shape[0] != rows_in:
+            raise ValueError("B has the wrong number of rows")
+        out = torch.empty((rows_out, k), dtype=self.tdtype, device=self.device)
+        self._check(self._lib.mnmf_spmm(self._h, int(bool(transpose)), k, B.data_ptr(), out.data_ptr()))
+        return out
+
+    def gram(self, A, B=None):
+        A = self._dev(A)
+        rows, k = A.shape
+        Bp = None
+        if B is not None:
+            B = self._dev(B)
+            if B.shape != A.shape:
+                raise ValueError("A and B must have the same shape")
+            Bp = B.data_ptr()
+        out = torch.empty((k, k), dtype=self.tdtype, device=self.device)
+        self._check(self._lib.mnmf_gram(self._h, rows, k, A.data_ptr(), Bp, out.data_ptr()))
+        return out
+
+    def update(self, A, num, G, G2=None, eps=1e-10, sqrt_mode=False):
+        A, num, G = self._dev(A), self._dev(num), self._dev(G)
+        rows, k = A.shape
+        if num.shape != A.shape or G.shape != (k, k):
+            raise ValueError("shape mismatch")
+        G2p = None
+        if G2 is not None:
+            G2 = self._dev(G2)
+            G2p = G2.data_ptr()
+        out = torch.empty_like(A)
+        self._check(self._lib.mnmf_update(self._h, rows, k, A.data_ptr(), num.data_ptr(), G.data_ptr(), G2p,
+                                          float(eps), int(bool(sqrt_mode)), out.data_ptr()))
+        return out
+
+    def diff_norm(self, A, B, kind="spectral"):
+        A, B = self._dev(A), self._dev(B)
+        if A.shape != B.shape:
+            raise ValueError("shape mismatch")
+        out = C.c_double()
+        self._check(self._lib.mnmf_diff_norm(self._h, A.shape[0], A.shape[1], A.data_ptr(), B.data_ptr(),
+                                             0 if kind == "spectral" else 1, C.byref(out)))
+        return out.value
+
+
+def build_segments(rowptr, seg_nnz, long_row=512):
+    """Host-only: the segment description set_matrix builds (no GPU needed; used by CPU tests)."""
+    lib = _lib.load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    s = _lib.MnmfSegments()
+    rc = lib.mnmf_build_segments(rp.ctypes.data, len(rp) - 1, int(seg_nnz), int(long_row), C.byref(s))
+    if rc != 0:
+        raise MnmfError(rc, "mnmf_build_segments")
+    try:
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(max(int(n), 1),))[: int(n)].astype(dt).copy()
+        return dict(seg_start=arr(s.seg_start, s.n_seg + 1, np.int64), seg_info=arr(s.seg_info, s.n_seg, np.int32),
+                    nzrow=arr(s.nzrow, s.n_nzrow, np.int32), empty_rows=arr(s.empty_rows, s.n_empty, np.int32),
+                    fix_row=arr(s.fix_row, s.n_fix, np.int32), fix_first=arr(s.fix_first, s.n_fix, np.int32),
+                    fix_count=arr(s.fix_count, s.n_fix, np.int32), n_carry=int(s.n_carry))
+    finally:
+        lib.mnmf_free_segments(C.byref(s))

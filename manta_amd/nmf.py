@@ -1,0 +1,114 @@
+"""Drop-in ``run_nmf`` for MANTA on MI355X.
+
+Same signature, return contract and exceptions as
+``manta._functions.nmf.run_nmf`` (manta/_functions/nmf/nmf_orchestrator.py:143-181 and its
+``_nmf_cpu``, :50-140); the multiplicative-update loops run in libmnmf.so on the GPU.
+``install()`` rebinds the name inside an installed MANTA so ``run_topic_analysis(nmf_method=...,
+topic_count=...)`` (manta/__init__.py:60-84) uses this engine unchanged.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from .init import (nmf_initialization_nndsvd, nmf_initialization_random,  # noqa: F401  (re-exported)
+                   nmtf_initialization_nndsvd_legacy, nmtf_initialization_random)
+
+_ENGINES: dict = {}
+
+
+def find_max_rank(sparse_matrix) -> int:
+    """``int(nnz / (m + n))``; CSC required (nmf_orchestrator.py:14-46)."""
+    if not sp.isspmatrix_csc(sparse_matrix):
+        raise ValueError("Input matrix must be in CSC (Compressed Sparse Column) format.")
+    m, n = sparse_matrix.shape
+    return int(sparse_matrix.count_nonzero() / (m + n))
+
+
+def _engine(dtype, device):
+    from .engine import Engine
+
+    key = (dtype, device)
+    if key not in _ENGINES:
+        _ENGINES[key] = Engine(device=device, dtype=dtype)
+    return _ENGINES[key]
+
+
+def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initialization_nndsvd, norm_thresh=0.001,
+            zero_threshold=0.00001, nmf_method: str = "nmf", console=None, *, dtype: Optional[str] = None,
+            device=None, max_iter: Optional[int] = None, fixed_iters: Optional[int] = None, check_every: int = 1,
+            W0=None, H0=None, S0=None, stats_out: Optional[dict] = None) -> dict:
+    """Factorise ``sparse_matrix`` (docs x vocab) into ``{"W": (m,k), "H": (k,V)[, "S": (k,k)]}``,
+    float64 C-contiguous ndarrays, exactly as the reference does.
+
+    Reference semantics kept on purpose (nmf_orchestrator.py:105-133):
+    ``num_of_topics == -1`` -> auto rank; ``init`` is always called (also for nmtf, where its result is
+    discarded and the legacy double NNDSVD is used, nmtf.py:224); pnmf ignores ``norm_thresh`` /
+    ``zero_threshold`` (:120); unknown methods raise ``ValueError``.
+
+    Keyword-only extras (not in the reference): ``dtype`` "fp64" (default; env MANTA_AMD_DTYPE) or
+    "fp32"; ``device``; ``max_iter`` / ``fixed_iters`` / ``check_every``; explicit ``W0``/``H0``/``S0``;
+    ``stats_out`` dict receives iteration count, norms and timings.
+    """
+    del console  # progress output is not reproduced
+    dtype = dtype or os.environ.get("MANTA_AMD_DTYPE", "fp64")
+    csc = sparse_matrix.tocsc()                                            # :168
+    topic_count = num_of_topics
+    if topic_count == -1:
+        topic_count = find_max_rank(csc)                                   # :105-106
+    if W0 is None or H0 is None:
+        w, h = init(csc, topic_count)                                      # :109
+    else:
+        w, h = W0, H0
+    if nmf_method not in ("nmf", "pnmf", "nmtf"):
+        raise ValueError(f"Unknown NMF method: {nmf_method}. Supported methods are: 'nmf', 'pnmf', 'nmtf'")  # :130
+    csr = csc.tocsr()                                                      # :116
+    eng = _engine(dtype, device)
+    eng.set_matrix(csr)
+    extra = dict(check_every=check_every)
+    if max_iter is not None:
+        extra["max_iter"] = max_iter
+    if fixed_iters:
+        extra["fixed_iters"] = fixed_iters
+    if nmf_method == "pnmf":
+        W, H, st = eng.run_pnmf(w, **extra)                                # thresholds ignored, :120
+        out = {"W": W, "H": H}
+    elif nmf_method == "nmf":
+        W, H, st = eng.run_nmf(w, h, norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)  # :122
+        out = {"W": W, "H": H}
+    else:
+        if S0 is None or W0 is None or H0 is None:
+            w, s, h = nmtf_initialization_nndsvd_legacy(csr, topic_count)  # nmtf.py:224
+        else:
+            s = S0
+        W, S, H, st = eng.run_nmtf(w, s, h, norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)  # :127
+        out = {"W": W, "S": S, "H": H}
+    out = {k_: np.ascontiguousarray(eng._host(v)) for k_, v in out.items()}
+    if any(v is None for v in out.values()):
+        raise RuntimeError(f"NMF computation failed for method: {nmf_method}")  # :133
+    if stats_out is not None:
+        stats_out.update(iters=st.iters, converged=st.converged, w_norm=st.w_norm, h_norm=st.h_norm,
+                         s_norm=st.s_norm, ms_total=st.ms_total, ms_kernels=st.ms_kernels)
+    return out
+
+
+def install() -> list:
+    """Rebind ``run_nmf`` inside an installed MANTA.  Callers bind the name at import time
+    (modeling_pipeline.py:10, optimization_pipeline.py:16), so the attribute is replaced on each
+    importing module.  Returns the module names that were patched."""
+    import importlib
+
+    patched = []
+    for name in ("manta._functions.nmf.nmf_orchestrator", "manta._functions.nmf", "manta._functions",
+                 "manta.pipeline.modeling_pipeline", "manta.pipeline.optimization_pipeline"):
+        try:
+            mod = importlib.import_module(name)
+        except Exception:
+            continue
+        if hasattr(mod, "run_nmf"):
+            setattr(mod, "run_nmf", run_nmf)
+            patched.append(name)
+    return patched

@@ -1,0 +1,149 @@
+"""Kernel-level parity on the GPU, through the C-ABI, against numpy/scipy float64.
+
+Tolerances: fp64 1e-12 relative Frobenius (summation order only); fp32 2e-6."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp64": 1e-12, "fp32": 2e-6}
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    d = np.linalg.norm(a - b)
+    n = np.linalg.norm(b)
+    return d / n if n > 0 else d
+
+
+def host(t):
+    return t.detach().cpu().double().numpy()
+
+
+def make_x(m, V, seed, dense_cols=2, empty_rows=(0, 7), empty_cols=(1,)):
+    """Sparse matrix with empty rows/columns and a few near-dense columns (long rows of X^T)."""
+    rng = np.random.RandomState(seed)
+    X = sp.random(m, V, density=min(0.5, 12.0 / V), format="lil", random_state=rng, data_rvs=lambda n: rng.rand(n) + 0.1)
+    for c in range(dense_cols):
+        col = 2 + 3 * c
+        rows = rng.rand(m) < (0.9 - 0.3 * c)
+        X[np.nonzero(rows)[0], col] = rng.rand(int(rows.sum())) + 0.1
+    for r in empty_rows:
+        if r < m:
+            X[r, :] = 0
+    for c in empty_cols:
+        X[:, c] = 0
+    X = X.tocsr()
+    X.eliminate_zeros()
+    X.sort_indices()
+    return X
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from manta_amd.engine import Engine
+
+    e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
+    yield e
+    for x in e.values():
+        x.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("k", [1, 5, 7, 10, 20, 50, 64, 100, 130, 260])
+def test_spmm_both_directions(engines, dtype, k):
+    eng = engines[dtype]
+    if dtype == "fp64" and k > 256:
+        pytest.skip("k > 256 unsupported in fp64")
+    X = make_x(1500, 700, seed=k)
+    assert (np.diff(X.tocsc().indptr) > 512).any(), "want at least one chunked (long) row in X^T"
+    eng.set_matrix(X)
+    rng = np.random.RandomState(k)
+    B = rng.rand(700, k)
+    A = rng.rand(1500, k)
+    assert rel(host(eng.spmm(B)), X @ B) <= TOL[dtype]
+    assert rel(host(eng.spmm(A, transpose=True)), X.T @ A) <= TOL[dtype]
+    # rows without nnz must come out exactly 0
+    out = host(eng.spmm(B))
+    assert np.all(out[np.diff(X.indptr) == 0] == 0)
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_spmm_long_document_rows_and_ragged(engines, dtype):
+    """Rows of X itself longer than the chunk threshold, single-nnz rows, a 1-row matrix."""
+    eng = engines[dtype]
+    rng = np.random.RandomState(3)
+    X = sp.random(40, 5000, density=0.3, format="csr", random_state=rng)   # ~1500 nnz per row
+    X.sort_indices()
+    eng.set_matrix(X)
+    B = rng.rand(5000, 12)
+    assert rel(host(eng.spmm(B)), X @ B) <= TOL[dtype]
+    A = rng.rand(40, 12)
+    assert rel(host(eng.spmm(A, transpose=True)), X.T @ A) <= TOL[dtype]
+    X1 = sp.csr_matrix(([1.5], ([0], [3])), shape=(1, 9))
+    eng.set_matrix(X1)
+    B = rng.rand(9, 4)
+    assert rel(host(eng.spmm(B)), X1 @ B) <= TOL[dtype]
+    X0 = sp.csr_matrix((5, 6))
+    eng.set_matrix(X0)
+    assert np.all(host(eng.spmm(rng.rand(6, 3))) == 0)
+
+
+def test_set_matrix_rejects_bad_input(engines):
+    import torch
+    from manta_amd.engine import MnmfError
+
+    eng = engines["fp32"]
+    rowptr = torch.tensor([0, 2, 3], dtype=torch.int64)
+    with pytest.raises(MnmfError, match="column index out of range"):
+        eng.set_matrix(rowptr=rowptr, colidx=torch.tensor([0, 9, 1], dtype=torch.int32),
+                       vals=torch.ones(3), shape=(2, 4))
+    with pytest.raises(MnmfError, match="rowptr"):
+        eng.set_matrix(rowptr=torch.tensor([0, 3, 2], dtype=torch.int64), colidx=torch.tensor([0, 1], dtype=torch.int32),
+                       vals=torch.ones(2), shape=(2, 4))
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("rows,k", [(1, 3), (1000, 5), (5000, 50), (3001, 70), (777, 130), (300, 200)])
+def test_gram(engines, dtype, rows, k):
+    eng = engines[dtype]
+    rng = np.random.RandomState(rows + k)
+    A = rng.rand(rows, k)
+    A[:, 0] *= 3.0                     # asymmetric content so a transposed write would show
+    B = rng.rand(rows, k) + np.arange(k)[None, :] * 0.01
+    assert rel(host(eng.gram(A)), A.T @ A) <= TOL[dtype]
+    assert rel(host(eng.gram(A, B)), A.T @ B) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("rows,k", [(1, 2), (999, 7), (4096, 50), (2000, 100), (500, 200)])
+def test_update(engines, dtype, rows, k):
+    eng = engines[dtype]
+    rng = np.random.RandomState(rows * 7 + k)
+    A = rng.rand(rows, k)
+    A[rng.rand(rows, k) < 0.3] = 0.0    # NNDSVD-style exact zeros must stay exactly zero
+    num = rng.rand(rows, k)
+    G = rng.rand(k, k)
+    G2 = rng.rand(k, k)
+    eps = 1e-10
+    want = A * (num / (A @ G + eps))
+    got = host(eng.update(A, num, G, eps=eps))
+    assert rel(got, want) <= TOL[dtype] * 5
+    assert np.all(got[A == 0] == 0)
+    want = A * np.sqrt(num / (A @ G + num @ G2 + eps))
+    got = host(eng.update(A, num, G, G2=G2, eps=eps, sqrt_mode=True))
+    assert rel(got, want) <= TOL[dtype] * 5
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_diff_norms(engines, dtype):
+    eng = engines[dtype]
+    rng = np.random.RandomState(5)
+    for rows, k in [(2000, 10), (300, 52), (50, 3)]:
+        A, B = rng.rand(rows, k), rng.rand(rows, k)
+        d = np.abs(A - B)
+        tol = 1e-10 if dtype == "fp64" else 1e-5
+        assert abs(eng.diff_norm(A, B) - np.linalg.norm(d, 2)) <= tol * np.linalg.norm(d, 2)
+        assert abs(eng.diff_norm(A, B, kind="fro") - np.linalg.norm(d, "fro")) <= tol * np.linalg.norm(d, "fro")
+    assert eng.diff_norm(A, A) == 0.0

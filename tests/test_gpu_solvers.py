@@ -1,0 +1,195 @@
+"""Solver-level parity on the GPU through the C-ABI: the three MU loops against (a) the golden
+vectors produced by the unmodified reference and (b) the CPU oracle on larger seeded inputs.
+
+Stated tolerances: relative Frobenius error fp64 <= 1e-10, fp32 <= 1e-4 (<= 200
+iterations); entries that are exactly 0 in the reference are exactly 0; top-15 rankings identical
+wherever adjacent reference scores differ by more than the tolerance."""
+import numpy as np
+import pytest
+
+from oracle import nmf_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp64": 1e-10, "fp32": 1e-4}
+FIXED = ["fixed_A_300x200_k5", "fixed_C_500x400_k7", "fixed_B_1000x1200_k10"]
+
+
+def rel(a, b):
+    d = np.linalg.norm(np.asarray(a, np.float64) - b)
+    n = np.linalg.norm(b)
+    return d / n if n > 0 else d
+
+
+def host(t):
+    return t.detach().cpu().double().numpy()
+
+
+def same_rankings(got, want, tol, top_n=15):
+    """Row-wise descending order of ``got`` equals that of ``want`` where reference gaps exceed tol."""
+    for g, w in zip(got, want):
+        order_w = np.flip(np.argsort(w))[:top_n]
+        order_g = np.flip(np.argsort(g))[:top_n]
+        scale = max(np.abs(w).max(), 1e-300)
+        for pos in range(top_n):
+            if order_w[pos] == order_g[pos]:
+                continue
+            # allowed only if the reference scores of the two candidates are within tolerance (tie)
+            assert abs(w[order_w[pos]] - w[order_g[pos]]) <= 10 * tol * scale, (pos, order_w, order_g)
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from manta_amd.engine import Engine
+
+    e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
+    yield e
+    for x in e.values():
+        x.close()
+
+
+def check_factors(got, want, dtype, zero_exact=True):
+    for key in want:
+        g = host(got[key])
+        assert g.shape == want[key].shape
+        assert np.all(np.isfinite(g))
+        assert rel(g, want[key]) <= TOL[dtype], (key, rel(g, want[key]))
+        if zero_exact and dtype == "fp64":
+            assert np.all(g[want[key] == 0] == 0), f"{key}: reference zeros must stay exactly 0"
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("name", FIXED)
+def test_nmf_fixed_iterations_vs_reference(engines, golden, name, dtype):
+    g = golden(name)
+    eng = engines[dtype]
+    eng.set_matrix(g["X"])
+    for N in g["Ns"]:
+        W, H, st = eng.run_nmf(g["W0"], g["H0"], fixed_iters=int(N), zero_threshold=1e-5)
+        assert st.iters == int(N)
+        check_factors({"W": W, "H": H}, {"W": g[f"nmf_W_{N}"], "H": g[f"nmf_H_{N}"]}, dtype)
+    N = int(g["Ns"][-1])
+    W, H, _ = eng.run_nmf(g["Wr0"], g["Hr0"], fixed_iters=N, zero_threshold=1e-5)
+    check_factors({"W": W, "H": H}, {"W": g["nmfr_W"], "H": g["nmfr_H"]}, dtype)
+    same_rankings(host(H), g["nmfr_H"], TOL[dtype])
+    same_rankings(host(W).T, g["nmfr_W"].T, TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("name", FIXED)
+def test_pnmf_fixed_iterations_vs_reference(engines, golden, name, dtype):
+    g = golden(name)
+    eng = engines[dtype]
+    eng.set_matrix(g["X"])
+    for N in g["Ns"]:
+        W, H, st = eng.run_pnmf(g["W0"], fixed_iters=int(N))
+        assert st.iters == int(N)
+        check_factors({"W": W, "H": H}, {"W": g[f"pnmf_W_{N}"], "H": g[f"pnmf_H_{N}"]}, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("name", FIXED)
+def test_nmtf_fixed_iterations_vs_reference(engines, golden, name, dtype):
+    g = golden(name)
+    eng = engines[dtype]
+    eng.set_matrix(g["X"])
+    for N in g["Ns"]:
+        W, S, H, st = eng.run_nmtf(g["Wt0"], g["St0"], g["Ht0"], fixed_iters=int(N), zero_threshold=1e-5)
+        assert st.iters == int(N)
+        check_factors({"W": W, "S": S, "H": H},
+                      {"W": g[f"nmtf_W_{N}"], "S": g[f"nmtf_S_{N}"], "H": g[f"nmtf_H_{N}"]}, dtype)
+    N = int(g["Ns"][-1])
+    W, S, H, _ = eng.run_nmtf(g["Wr0"], g["Sr0"], g["Hr0"], fixed_iters=N, zero_threshold=1e-5)
+    check_factors({"W": W, "S": S, "H": H}, {"W": g["nmtfr_W"], "S": g["nmtfr_S"], "H": g["nmtfr_H"]}, dtype)
+
+
+@pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
+def test_run_nmf_converged_vs_reference(golden, method):
+    """The drop-in entry point, called as the pipeline calls it, from the reference's own init:
+    same stopping iteration, same outputs (fp64), same keys; pnmf keeps the break-before-assign rule."""
+    import manta_amd
+
+    g = golden(f"converged_D_600x500_k6_{method}")
+    stats = {}
+    kw = dict(W0=g["W0"], H0=g["H0"])
+    if method == "nmtf":
+        kw = dict(W0=g["Wt0"], H0=g["Ht0"], S0=g["St0"])
+    out = manta_amd.run_nmf(int(g["k"]), g["X"], norm_thresh=0.005, nmf_method=method, dtype="fp64",
+                            stats_out=stats, **kw)
+    assert sorted(out) == sorted(["W", "H"] + (["S"] if method == "nmtf" else []))
+    iters = int(g["iters"]) - (1 if method == "pnmf" else 0)
+    assert stats["iters"] == iters and stats["converged"]
+    for key in out:
+        assert out[key].dtype == np.float64 and out[key].flags["C_CONTIGUOUS"]
+        want = g["out_" + key]
+        assert rel(out[key], want) <= TOL["fp64"], (key, rel(out[key], want))
+        assert np.all(out[key][want == 0] == 0)
+    S = out.get("S")
+    w_words, w_docs = oc.topic_rankings(g["out_H"], g["out_W"], S=g.get("out_S"))
+    g_words, g_docs = oc.topic_rankings(out["H"], out["W"], S=S)
+    assert np.array_equal(w_words, g_words)
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
+def test_medium_zipf_vs_oracle(engines, dtype, method):
+    """5000 x 8000 Zipf TF-IDF (the SURVEY calibration matrix), k = 10 and 50, 30 iterations."""
+    import torch
+    from manta_amd.synth import zipf_tfidf_csr, to_scipy
+
+    rowptr, col, val = zipf_tfidf_csr(5000, 8000, 0.004, seed=77, device="cpu", dtype=torch.float64)
+    X = to_scipy(rowptr, col, val, (5000, 8000))
+    eng = engines[dtype]
+    eng.set_matrix(X)
+    rng = np.random.RandomState(42)
+    for k in (10, 50):
+        W0 = rng.uniform(0, X.max(), (5000, k))
+        H0 = rng.uniform(0, X.max(), (k, 8000))
+        S0 = rng.uniform(0, X.max(), (k, k))
+        N = 30
+        if method == "nmf":
+            want = oc.basic_nmf(X, W0, H0, zero_threshold=1e-5, n_iter=N, check=False)
+            W, H, _ = eng.run_nmf(W0, H0, fixed_iters=N, zero_threshold=1e-5)
+            got = {"W": W, "H": H}
+        elif method == "pnmf":
+            want = oc.projective_nmf(X, W0, n_iter=N, check=False)
+            W, H, _ = eng.run_pnmf(W0, fixed_iters=N)
+            got = {"W": W, "H": H}
+        else:
+            want = oc.nmtf_core(X, W0, S0, H0, zero_threshold=1e-5, n_iter=N, check=False)
+            W, S, H, _ = eng.run_nmtf(W0, S0, H0, fixed_iters=N, zero_threshold=1e-5)
+            got = {"W": W, "S": S, "H": H}
+        check_factors(got, want, dtype, zero_exact=False)
+        same_rankings(host(got["H"]), want["H"], TOL[dtype])
+
+
+def test_convergence_norms_match_oracle(engines):
+    """Per-iteration spectral norms (computed from k x k Grams on the GPU) equal numpy's SVD norms."""
+    g_name = "fixed_B_1000x1200_k10"
+    from conftest import load_golden
+
+    g = load_golden(g_name)
+    eng = engines["fp64"]
+    eng.set_matrix(g["X"])
+    st_o = {}
+    oc.basic_nmf(g["X"], g["W0"].copy(), g["H0"].copy(), n_iter=7, stats=st_o)
+    _, _, st = eng.run_nmf(g["W0"], g["H0"], fixed_iters=7, force_check=True)
+    assert abs(st.w_norm - st_o["w_norm"]) <= 1e-9 * st_o["w_norm"]
+    assert abs(st.h_norm - st_o["h_norm"]) <= 1e-9 * st_o["h_norm"]
+    st_o = {}
+    oc.nmtf_core(g["X"], g["Wt0"].copy(), g["St0"].copy(), g["Ht0"].copy(), n_iter=5, stats=st_o)
+    _, _, _, st = eng.run_nmtf(g["Wt0"], g["St0"], g["Ht0"], fixed_iters=5, force_check=True)
+    for key in ("w_norm", "h_norm", "s_norm"):
+        assert abs(getattr(st, key) - st_o[key]) <= 1e-9 * st_o[key]
+
+
+def test_determinism(engines):
+    """No atomics anywhere: two runs give bit-identical factors."""
+    from conftest import load_golden
+
+    g = load_golden("fixed_B_1000x1200_k10")
+    eng = engines["fp32"]
+    eng.set_matrix(g["X"])
+    a = eng.run_nmf(g["Wr0"], g["Hr0"], fixed_iters=10)
+    b = eng.run_nmf(g["Wr0"], g["Hr0"], fixed_iters=10)
+    assert np.array_equal(host(a[0]), host(b[0])) and np.array_equal(host(a[1]), host(b[1]))
