@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NMF multiplicative-update iterations/second on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one full MU iteration (H update, W update, and -- like the reference, nmf_basic.py:52-53
+-- both convergence norms) of standard NMF on a synthetic Zipf TF-IDF matrix, BASELINE.json config 1:
+1M docs x 100k vocab, ~0.1 % density, k = 50, fp32.  Inputs are resident in HBM before the timed region.
+For N > 1 the documents (rows of X and W) are sharded over the ranks (total work fixed: strong scaling);
+the k x V partial of X^T.W and the k x k Grams are all-reduced with RCCL every iteration.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) including
+  roofline     -- dominant kernel's algorithmic bytes / its HIP-event time, against 8 TB/s
+  cpu_baseline -- the CPU oracle (numpy/scipy port of the reference loop) timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (method, m, V, density, k)
+    "c1": ("nmf", 20_000, 30_000, 0.003, 10),
+    "c2": ("nmf", 1_000_000, 100_000, 0.001, 50),
+    "c3": ("pnmf", 1_000_000, 100_000, 0.001, 100),
+    "c4": ("nmtf", 2_000_000, 200_000, 0.0005, 20),
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--m", type=int, default=0)
+    ap.add_argument("--V", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--density", type=float, default=0.0)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from manta_amd.engine import Engine
+    from manta_amd.synth import zipf_tfidf_csr
+
+    method, m, V, density, k = CONFIGS[args.config]
+    m, V, k = args.m or m, args.V or V, args.k or k
+    density = args.density or density
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tdt = torch.float32 if args.dtype == "fp32" else torch.float64
+    # ---- this rank's shard of the documents (seed 1234 + rank), df / avg length combined over ranks
+    m_lo = (m * rank) // world
+    m_hi = (m * (rank + 1)) // world
+    m_loc = m_hi - m_lo
+    t_gen = time.time()
+    rowptr, col, val = zipf_tfidf_csr(m_loc, V, density, seed=1234 + rank, device=dev, dtype=torch.float64)
+    if world > 1:
+        # values were computed from local df; redo idf with the global df so the matrix is one TF-IDF
+        df = torch.bincount(col.long(), minlength=V).double()
+        df_g = df.clone()
+        dist.all_reduce(df_g)
+        scale = torch.log2((1.0 + m) / df_g.clamp(min=1.0)) / torch.log2((1.0 + m_loc) / df.clamp(min=1.0)).clamp(min=1e-30)
+        val = val * scale[col.long()]
+    val = val.to(tdt)
+    nnz_loc = int(col.numel())
+    nnz = nnz_loc
+    if world > 1:
+        t = torch.tensor([nnz_loc], device=dev, dtype=torch.int64)
+        dist.all_reduce(t)
+        nnz = int(t.item())
+    xmax = float(val.max())
+    if world > 1:
+        t = torch.tensor([xmax], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        xmax = float(t.item())
+    t_gen = time.time() - t_gen
+
+    eng = Engine(device=local_rank, dtype=args.dtype)
+    t_prep = time.time()
+    eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(m_loc, V))
+    torch.cuda.synchronize()
+    t_prep = time.time() - t_prep
+    if world > 1:
+        eng.set_process_group()
+
+    # ---- seeded uniform(0, max X) init (the reference's nmf_initialization_random), seed 42
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    H0 = torch.rand((k, V), generator=g, device=dev, dtype=torch.float64).mul_(xmax).to(tdt)
+    S0 = torch.rand((k, k), generator=g, device=dev, dtype=torch.float64).mul_(xmax).to(tdt)
+    g.manual_seed(4242 + rank)
+    W0 = torch.rand((m_loc, k), generator=g, device=dev, dtype=torch.float64).mul_(xmax).to(tdt)
+
+    def run(n, profile=False, check=True):
+        kw = dict(fixed_iters=n, force_check=check, check_every=1, finalize=False, profile=profile)
+        if method == "nmf":
+            return eng.run_nmf(W0, H0, **kw)[-1]
+        if method == "pnmf":
+            return eng.run_pnmf(W0, **kw)[-1]
+        return eng.run_nmtf(W0, S0, H0, **kw)[-1]
+
+    if args.warmup > 0:
+        run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    st = run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+    value = args.steps / dt
+
+    # ---- throughput mode (no per-iteration norms) and per-kernel HIP-event times, outside the timed region
+    barrier()
+    t1 = time.perf_counter()
+    run(args.steps, check=False)
+    barrier()
+    dt_nocheck = time.perf_counter() - t1
+    stp = run(args.steps, profile=True)
+    barrier()
+
+    sv = 4 if args.dtype == "fp32" else 8
+    xb = nnz_loc * (sv + 4)
+    phases = {n: v / args.steps for n, v in stp.phase_ms.items()}
+    alg_bytes = {
+        # stream X once, read the dense factor once (compulsory), write the product once
+        "spmm_x": xb + (m_loc + 1) * 8 + V * k * sv + m_loc * k * sv,
+        "spmm_xt": xb + (V + 1) * 8 + m_loc * k * sv + V * k * sv,
+    }
+    dom = max(alg_bytes, key=lambda n: phases.get(n, 0.0))
+    dom_ms = phases[dom]
+    achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "spmm_stream_kernel (" + ("X^T.W" if dom == "spmm_xt" else "X.H^T") + ")",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(dom_ms, 4),
+                "phase_ms_per_iter": {n: round(v, 4) for n, v in phases.items() if v > 0},
+                "iteration_bytes_model": st.bytes_model,
+                "iteration_frac_of_hbm": round(st.bytes_model * value / world / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- CPU baseline: the oracle (numpy/scipy port of the reference loop) on a bounded row sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(method, rowptr, col, val, m_loc, V, k, W0, S0, H0, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "nmf_mu_iterations_per_sec", "value": round(value, 3), "unit": "iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "f64", "data": "synthetic",
+            "config": {"workload": f"{method} MU, {m} docs x {V} vocab, density {density}, k={k} "
+                                   f"(BASELINE.json configs[{sorted(CONFIGS).index(args.config)}])",
+                       "nnz": nnz, "method": method, "parallelism": f"doc-shard x{world}",
+                       "convergence_check": "every iteration (as the reference)",
+                       "init": "uniform(0, max X), seed 42", "matrix": "Zipf(1.1) TF-IDF, seed 1234+rank"},
+            "value_without_convergence_check": round(args.steps / dt_nocheck, 3),
+            "roofline": roofline, "cpu_baseline": cpu,
+            "setup_s": {"generate": round(t_gen, 2), "set_matrix": round(t_prep, 2)},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(method, rowptr, col, val, m, V, k, W0, S0, H0, budget_s):
+    """Time the CPU oracle on the first rows of the same matrix; extrapolate linearly in rows."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    from oracle import nmf_oracle as oc
+
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    ms = min(m, 100_000)
+    end = int(rowptr[ms].item())
+    X = sp.csr_matrix((val[:end].double().cpu().numpy(), col[:end].cpu().numpy(), rowptr[: ms + 1].cpu().numpy()),
+                      shape=(ms, V))
+    W = W0[:ms].double().cpu().numpy()
+    H = H0.double().cpu().numpy()
+    S = S0.double().cpu().numpy()
+    def call(n):
+        t0 = time.perf_counter()
+        if method == "nmf":
+            oc.basic_nmf(X, W, H, zero_threshold=0.0, n_iter=n, check=True)
+        elif method == "pnmf":
+            oc.projective_nmf(X, W, zero_threshold=0.0, n_iter=n, check=True)
+        else:
+            oc.nmtf_core(X, W, S, H, zero_threshold=0.0, n_iter=n, check=True)
+        return time.perf_counter() - t0
+
+    t_first = call(1)
+    iters = max(2, min(20, int(budget_s / max(t_first, 1e-3))))
+    el = call(iters)
+    per_iter_sample = el / iters
+    per_iter_full = per_iter_sample * (m / ms)
+    return {"value": round(1.0 / per_iter_full, 5), "unit": "iter/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} iterations of the CPU oracle (float64, per-iteration norms as shipped) on the first "
+                      f"{ms} of {m} documents; seconds/iteration scaled by {m / ms:.1f}x (linear in rows) to the full matrix",
+            "sample_seconds_per_iter": round(per_iter_sample, 3)}
+
+
+if __name__ == "__main__":
+    main()
