@@ -284,7 +284,8 @@ class Engine : public ImplBase {
     constexpr int NG = kWave / LPR;
     const int64_t waves = cdiv(M.n_seg, NG);
     if (waves > 0) {
-      spmm_stream_kernel<T, LPR, VPL, U><<<(unsigned)cdiv(waves, 4), 256, 0, st()>>>(
+      auto kern = (&M == &Xt) ? spmm_stream_kernel<T, LPR, VPL, U, 1> : spmm_stream_kernel<T, LPR, VPL, U, 0>;
+      kern<<<(unsigned)cdiv(waves, 4), 256, 0, st()>>>(
           M.seg_start.template as<int64_t>(), M.seg_info.template as<int32_t>(), M.n_seg, M.cols.template as<uint32_t>(), M.vals.template as<T>(),
           M.nzrow.template as<int32_t>(), B, ld, out, M.carry.template as<T>());
       E_LAUNCH();

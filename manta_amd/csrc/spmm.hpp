@@ -12,7 +12,8 @@
 
 namespace mnmf {
 
-template <typename T, int LPR, int VPL, int U>
+// DIR only names the instantiation (0: X.B, 1: X^T.B) so profiles list the two directions apart.
+template <typename T, int LPR, int VPL, int U, int DIR>
 __global__ __launch_bounds__(256) void spmm_stream_kernel(
     const int64_t* __restrict__ seg_start, const int32_t* __restrict__ seg_info, int64_t n_seg,
     const uint32_t* __restrict__ cols, const T* __restrict__ vals, const int32_t* __restrict__ nzrow,

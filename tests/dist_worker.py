@@ -1,0 +1,111 @@
+"""Worker for the world_size-2 tests (launched with torch.distributed.run).
+
+mode=emulate (CPU, gloo): every rank runs the engine's per-rank schedule in numpy on its document
+shard and sums exactly what engine.hip all-reduces, at the same points; the result must equal the
+unsharded oracle.  This pins the sharding algorithm (what is exchanged, and when).
+mode=engine (GPU): the real HIP engine, two ranks on one GPU, exchange staged through gloo.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import load_golden  # noqa: E402
+from manta_amd.dist import shard_csr  # noqa: E402
+from oracle import nmf_oracle as oc  # noqa: E402
+
+
+def allreduce(a):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    dist.all_reduce(t)
+    return t.numpy()
+
+
+def emulate(method, X, W, H, S, N):
+    """Per-rank schedule of engine.hip (run_nmf / run_pnmf / run_nmtf) with its exchange points."""
+    if method == "nmf":
+        for _ in range(N):
+            ex = allreduce(np.concatenate([(X.T @ W).ravel(), (W.T @ W).ravel()]))   # [X^T W | W^T W]
+            k, V = H.shape
+            num_h, wtw = ex[:V * k].reshape(V, k).T, ex[V * k:].reshape(k, k)
+            H = H * (num_h / (wtw @ H + oc.NMF_EPS))
+            W = W * ((X @ H.T) / (W @ (H @ H.T) + oc.NMF_EPS))
+        return {"W": W, "H": H}
+    if method == "pnmf":
+        k = W.shape[1]
+        V = X.shape[1]
+        for _ in range(N):
+            ex = allreduce(np.concatenate([(X.T @ W).ravel(), (W.T @ W).ravel()]))   # [vtw | wtw]
+            vtw, wtw = ex[:V * k].reshape(V, k), ex[V * k:].reshape(k, k)
+            pay = X @ vtw
+            wt_pay = allreduce(W.T @ pay)
+            W = W * np.sqrt(pay / (W @ wt_pay + pay @ wtw + oc.PNMF_EPS))
+        W = W.copy()
+        W[W < oc.PNMF_ZERO] = 0
+        nrm = np.sqrt(np.diag(allreduce(W.T @ W)))
+        nrm[nrm < 10 * np.finfo(np.float64).eps] = 1.0
+        W = W / nrm
+        return {"W": W, "H": allreduce(np.ascontiguousarray((X.T @ W))).T}
+    k = W.shape[1]
+    V = X.shape[1]
+    for _ in range(N):
+        hhT = H @ H.T
+        W1 = W * ((X @ (H.T @ S.T)) / (W @ (S @ hhT @ S.T) + oc.NMTF_EPS))
+        ex = allreduce(np.concatenate([(X.T @ W1).ravel(), (W1.T @ W1).ravel()]))      # [P^T | w1^T w1]
+        Pt, g = ex[:V * k].reshape(V, k), ex[V * k:].reshape(k, k)
+        S1 = S * ((Pt.T @ H.T) / (g @ S @ hhT + oc.NMTF_EPS))
+        H1 = H * ((S1.T @ Pt.T) / ((S1.T @ g @ S1) @ H + oc.NMTF_EPS))
+        W, S, H = W1, S1, H1
+    return {"W": W, "S": S, "H": H}
+
+
+def main():
+    mode, method = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g = load_golden("fixed_B_1000x1200_k10")
+    X = g["X"]
+    N = 6
+    W0, H0, S0 = g["Wr0"], g["Hr0"], g["Sr0"]
+    Xl, lo, hi = shard_csr(X, rank, world)
+    if method == "nmf":
+        want = oc.basic_nmf(X, W0, H0, zero_threshold=0.0, n_iter=N, check=False)
+    elif method == "pnmf":
+        want = oc.projective_nmf(X, W0, n_iter=N, check=False)
+    else:
+        want = oc.nmtf_core(X, W0, S0, H0, zero_threshold=0.0, n_iter=N, check=False)
+    if mode == "emulate":
+        got = emulate(method, Xl.tocsr(), W0[lo:hi].copy(), H0.copy(), S0.copy(), N)
+        tol = 1e-11
+    else:
+        from manta_amd.dist import run_sharded
+
+        dtype = sys.argv[3]
+        kw = dict(fixed_iters=N, zero_threshold=0.0) if method != "pnmf" else dict(fixed_iters=N)
+        res = run_sharded(method, Xl, W0[lo:hi], H0, S0, dtype=dtype, device=0, **kw)
+        keys = ["W", "S", "H"] if method == "nmtf" else ["W", "H"]
+        got = {k_: v.cpu().double().numpy() for k_, v in zip(keys, res[:-1])}
+        tol = 1e-10 if dtype == "fp64" else 1e-4
+    for key in want:
+        ref = want[key][lo:hi] if key == "W" else want[key]
+        err = np.linalg.norm(got[key] - ref) / np.linalg.norm(ref)
+        assert err <= tol, f"rank {rank} {method} {key}: rel err {err}"
+    # every rank must hold the same replicated H
+    h = torch.from_numpy(np.ascontiguousarray(got["H"]))
+    hs = [torch.empty_like(h) for _ in range(world)]
+    dist.all_gather(hs, h)
+    assert all(torch.equal(hs[0], x) for x in hs), "H differs between ranks"
+    dist.barrier()
+    if rank == 0:
+        print(f"OK {mode} {method}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

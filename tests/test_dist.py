@@ -1,0 +1,53 @@
+"""world_size-2 coverage of the document-sharded path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def launch(args, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "OK" in r.stdout
+
+
+def test_partition_by_nnz():
+    from manta_amd.dist import partition_rows_by_nnz, shard_csr
+
+    rng = np.random.RandomState(0)
+    lens = rng.poisson(30, 1000)
+    lens[:100] = 300
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    for world in (1, 2, 4, 8):
+        b = partition_rows_by_nnz(rowptr, world)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0)
+        per = np.diff(rowptr[b])
+        assert per.sum() == rowptr[-1]
+        assert per.max() <= rowptr[-1] / world + 300
+    X = sp.random(50, 30, density=0.2, format="csr", random_state=1)
+    parts = [shard_csr(X, r, 3)[0] for r in range(3)]
+    assert (sp.vstack(parts) != X).nnz == 0
+    # more ranks than rows with nnz: empty shards are legal
+    b = partition_rows_by_nnz(np.array([0, 5]), 4)
+    assert b[0] == 0 and b[-1] == 1
+
+
+@pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
+def test_sharded_schedule_gloo_cpu(method):
+    launch(["emulate", method], 29611 + ["nmf", "pnmf", "nmtf"].index(method))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
+def test_sharded_engine_two_ranks_one_gpu(method, dtype):
+    launch(["engine", method, dtype], 29631 + ["nmf", "pnmf", "nmtf"].index(method) + (3 if dtype == "fp32" else 0))
