@@ -129,24 +129,36 @@ int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void
 int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes);
 
 /* -- host-only helpers (no GPU needed; used by the CPU tests) ------------------------------ */
-/* Build the streaming-segment description of a CSR row pointer exactly as set_matrix does.
- * Outputs are malloc'ed arrays the caller frees with mnmf_free_host.  See DESIGN.md "stream layout". */
+/* Build the streaming-segment description exactly as the engine does (DESIGN.md "stream layout").
+ * A matrix is a sequence of PIECES (runs of nnz with one destination).  mnmf_build_segments takes a CSR
+ * row pointer (one piece per non-empty row); mnmf_build_segments_pieces takes explicit pieces in
+ * processing order (piece i = nnz [piece_start[i], piece_start[i+1]) of output row piece_row[i]), which
+ * is how the document-blocked X^T is described.  Pieces longer than sub_piece are cut; rows made of
+ * several (sub-)pieces are summed from carry slots.  Outputs are malloc'ed; free with mnmf_free_segments. */
 typedef struct {
   int64_t n_seg;       /* segments */
-  int64_t* seg_start;  /* [n_seg+1] nnz offsets */
-  int32_t* seg_info;   /* [n_seg] >=0: index into nzrow of the first row; <0: ~carry slot (chunk of a long row) */
-  int64_t n_nzrow;
-  int32_t* nzrow;      /* ids of non-empty rows, ascending */
+  int64_t* seg_start;  /* [n_seg] offset of the segment's first nnz */
+  int32_t* seg_len;    /* [n_seg] nnz in the segment (0: padding segment) */
+  int32_t* seg_info;   /* [n_seg] index into dest of the segment's first sub-piece */
+  int64_t n_dest;      /* sub-pieces */
+  int32_t* dest;       /* [n_dest] >=0: output row; <0: ~carry slot */
+  int64_t* piece_end;  /* [n_dest] position of the sub-piece's last nnz (carries the end flag) */
   int64_t n_empty;
-  int32_t* empty_rows; /* ids of empty rows */
-  int64_t n_fix;       /* long rows that were chunked */
+  int32_t* empty_rows; /* rows without nnz */
+  int64_t n_fix;       /* rows summed from carry slots */
   int32_t* fix_row;    /* [n_fix] row id */
   int32_t* fix_first;  /* [n_fix] first carry slot */
   int32_t* fix_count;  /* [n_fix] number of carry slots */
   int64_t n_carry;
 } mnmf_segments;
-int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t long_row,
+int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t sub_piece,
                         mnmf_segments* out);
+/* piece_block (may be NULL): document block of each piece, -1 = not blocked.  With piece_block and
+ * xcd_group > 0 the segments are emitted in XCD-affine order: workgroup g (xcd_group segments each)
+ * takes the next segments of the blocks b with b mod 8 == g mod 8; lists are padded with empty segments. */
+int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
+                               int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece,
+                               int xcd_group, mnmf_segments* out);
 void mnmf_free_segments(mnmf_segments* s);
 /* lambda_max of a symmetric n x n matrix (row-major, double) by cyclic Jacobi. */
 double mnmf_sym_lambda_max(const double* a, int n);

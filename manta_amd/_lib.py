@@ -24,8 +24,9 @@ class MnmfStats(C.Structure):
 
 
 class MnmfSegments(C.Structure):
-    _fields_ = [("n_seg", C.c_int64), ("seg_start", C.POINTER(C.c_int64)), ("seg_info", C.POINTER(C.c_int32)),
-                ("n_nzrow", C.c_int64), ("nzrow", C.POINTER(C.c_int32)),
+    _fields_ = [("n_seg", C.c_int64), ("seg_start", C.POINTER(C.c_int64)), ("seg_len", C.POINTER(C.c_int32)),
+                ("seg_info", C.POINTER(C.c_int32)),
+                ("n_dest", C.c_int64), ("dest", C.POINTER(C.c_int32)), ("piece_end", C.POINTER(C.c_int64)),
                 ("n_empty", C.c_int64), ("empty_rows", C.POINTER(C.c_int32)),
                 ("n_fix", C.c_int64), ("fix_row", C.POINTER(C.c_int32)), ("fix_first", C.POINTER(C.c_int32)),
                 ("fix_count", C.POINTER(C.c_int32)), ("n_carry", C.c_int64)]
@@ -50,6 +51,8 @@ SIGNATURES = {
     "mnmf_diff_norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "mnmf_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "mnmf_build_segments": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(MnmfSegments)]),
+    "mnmf_build_segments_pieces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                             C.c_int64, C.c_int, C.POINTER(MnmfSegments)]),
     "mnmf_free_segments": (None, [C.POINTER(MnmfSegments)]),
     "mnmf_sym_lambda_max": (C.c_double, [C.c_void_p, C.c_int]),
 }

@@ -9,7 +9,6 @@ namespace mnmf {
 
 constexpr int kWave = 64;
 constexpr uint32_t kEndFlag = 0x80000000u;  // top bit of a stream column id = last nnz of its row
-constexpr int64_t kLongRow = 512;           // rows longer than this are chunked (no end flag)
 
 template <typename T, int N>
 struct alignas(sizeof(T) * N) Vec {

@@ -68,6 +68,21 @@ struct DevBuf {
   U* as() const { return reinterpret_cast<U*>(p); }
 };
 
+// Tunables (environment overrides are for experiments; defaults are what the benchmarks use).
+struct Tune {
+  int64_t x_q = 512;                  // target nnz per segment, X stream
+  int64_t xt_q = 512;                 // target nnz per segment, X^T stream
+  int64_t xt_block_bytes = 2 << 20;   // bytes of W rows per document block of X^T
+  int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
+  Tune() {
+    auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
+    x_q = geti("MNMF_X_Q", x_q);
+    xt_q = geti("MNMF_XT_Q", xt_q);
+    xt_block_bytes = geti("MNMF_XT_BLOCK_BYTES", xt_block_bytes);
+    xcd_affinity = (int)geti("MNMF_XCD_AFFINITY", xcd_affinity);
+  }
+};
+
 struct PhaseTimer {
   // HIP events on the solver's stream at phase boundaries; summed after the loop has drained.
   static constexpr int kMaxPhases = 8;
@@ -97,12 +112,15 @@ struct PhaseTimer {
 
 template <typename T>
 struct StreamMat {
-  int64_t rows = 0, tab_rows = 0, nnz = 0;  // out rows, gather-table rows
-  DevBuf cols, vals;                         // uint32 (flagged), T
-  std::vector<int64_t> h_rowptr;
+  int64_t rows = 0, tab_rows = 0, nnz = 0;  // output rows, gather-table rows
+  DevBuf cols, vals;                         // uint32 gather index (end-flagged), T
+  HostPieces pieces;                         // processing-order pieces (host)
+  bool built = false, flags_set = false;
+  int block_shift = -1;                      // X^T only: log2(documents per block)
   // segment description for the current seg_q
-  int64_t seg_q = -1, n_seg = 0, n_nzrow = 0, n_empty = 0, n_fix = 0, n_carry = 0;
-  DevBuf seg_start, seg_info, nzrow, empty_rows, fix_row, fix_first, fix_count, carry;
+  int64_t seg_q = -1, n_seg = 0, n_empty = 0, n_fix = 0, n_carry = 0;
+  int seg_group = -1;
+  DevBuf seg_start, seg_len, seg_info, dest, empty_rows, fix_row, fix_first, fix_count, carry;
 };
 
 inline int pow2_ceil(int x) {
@@ -120,9 +138,12 @@ class Engine : public ImplBase {
   }
 
   mnmf_ctx* ctx;
+  Tune tune;
   int64_t m = 0, V = 0, nnz = 0;
   bool have_matrix = false;
   StreamMat<T> X, Xt;
+  std::vector<int64_t> h_rowptr;
+  DevBuf d_rowptr;
   // solver workspaces
   DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD;
   double* h_pinned = nullptr;
@@ -168,50 +189,42 @@ class Engine : public ImplBase {
     V = V_;
     nnz = nnz_;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    X.h_rowptr.assign(m + 1, 0);
+    h_rowptr.assign(m + 1, 0);
     if (on_device) {
-      E_HIP(hipMemcpyAsync(X.h_rowptr.data(), rowptr, (m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st()));
+      E_HIP(hipMemcpyAsync(h_rowptr.data(), rowptr, (m + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st()));
       E_HIP(hipStreamSynchronize(st()));
     } else {
-      std::memcpy(X.h_rowptr.data(), rowptr, (m + 1) * sizeof(int64_t));
+      std::memcpy(h_rowptr.data(), rowptr, (m + 1) * sizeof(int64_t));
     }
-    if (X.h_rowptr[0] != 0 || X.h_rowptr[m] != nnz) return fail(MNMF_EINVAL, "set_matrix: rowptr[0] must be 0 and rowptr[m] == nnz");
+    if (h_rowptr[0] != 0 || h_rowptr[m] != nnz) return fail(MNMF_EINVAL, "set_matrix: rowptr[0] must be 0 and rowptr[m] == nnz");
     for (int64_t r = 0; r < m; ++r)
-      if (X.h_rowptr[r + 1] < X.h_rowptr[r]) return fail(MNMF_EINVAL, "set_matrix: rowptr not monotone");
+      if (h_rowptr[r + 1] < h_rowptr[r]) return fail(MNMF_EINVAL, "set_matrix: rowptr not monotone");
+    X = StreamMat<T>();
+    Xt = StreamMat<T>();
     X.rows = m;
     X.tab_rows = V;
     X.nnz = nnz;
-    X.seg_q = -1;
     Xt.rows = V;
     Xt.tab_rows = m;
     Xt.nnz = nnz;
-    Xt.seg_q = -1;
-    Xt.h_rowptr.assign(V + 1, 0);
     const size_t n = (size_t)std::max<int64_t>(nnz, 1);
     E_HIP(X.cols.ensure(n * 4));
     E_HIP(X.vals.ensure(n * sizeof(T)));
-    E_HIP(Xt.cols.ensure(n * 4));
-    E_HIP(Xt.vals.ensure(n * sizeof(T)));
+    E_HIP(d_rowptr.ensure((m + 1) * 8));
+    pieces_from_rowptr(h_rowptr.data(), m, X.pieces);
+    X.built = true;
     if (nnz == 0) {
+      Xt.pieces.start.assign(1, 0);
+      Xt.built = true;
       have_matrix = true;
       return 0;
     }
     E_HIP(hipMemcpyAsync(X.cols.p, colidx, nnz * 4, kind, st()));
     E_HIP(hipMemcpyAsync(X.vals.p, vals, nnz * sizeof(T), kind, st()));
-    DevBuf d_rp, d_trp, rowid, iota, keys_out, perm, tmp, d_max;
-    E_HIP(d_rp.ensure((m + 1) * 8));
-    E_HIP(d_trp.ensure((V + 1) * 8));
-    E_HIP(rowid.ensure(n * 4));
-    E_HIP(iota.ensure(n * 4));
-    E_HIP(keys_out.ensure(n * 4));
-    E_HIP(perm.ensure(n * 4));
-    E_HIP(hipMemcpyAsync(d_rp.p, X.h_rowptr.data(), (m + 1) * 8, hipMemcpyHostToDevice, st()));
-    const int TB = 256;
-    expand_rowids_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(d_rp.template as<int64_t>(), m, nnz, rowid.template as<uint32_t>(),
-                                                                   iota.template as<uint32_t>());
-    E_LAUNCH();
+    E_HIP(hipMemcpyAsync(d_rowptr.p, h_rowptr.data(), (m + 1) * 8, hipMemcpyHostToDevice, st()));
     // validate column ids before anything gathers through them
     {
+      DevBuf tmp, d_max;
       size_t bytes = 0;
       E_HIP(d_max.ensure(4));
       E_HIP(rocprim::reduce(nullptr, bytes, X.cols.template as<uint32_t>(), d_max.template as<uint32_t>(), 0u, (size_t)nnz,
@@ -224,30 +237,95 @@ class Engine : public ImplBase {
       E_HIP(hipStreamSynchronize(st()));
       if ((int64_t)mx >= V) return fail(MNMF_EINVAL, "set_matrix: column index out of range");
     }
-    // stable sort of nnz by column: rows stay ascending inside each column of X^T
-    {
-      int bits = 1;
-      while (((int64_t)1 << bits) < V) ++bits;
-      size_t bytes = 0;
-      E_HIP(rocprim::radix_sort_pairs(nullptr, bytes, X.cols.template as<uint32_t>(), keys_out.template as<uint32_t>(),
-                                      iota.template as<uint32_t>(), perm.template as<uint32_t>(), (size_t)nnz, 0u, (unsigned)bits, st()));
-      E_HIP(tmp.ensure(bytes));
-      E_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, X.cols.template as<uint32_t>(), keys_out.template as<uint32_t>(),
-                                      iota.template as<uint32_t>(), perm.template as<uint32_t>(), (size_t)nnz, 0u, (unsigned)bits, st()));
-    }
-    lower_bound_ptr_kernel<<<(unsigned)cdiv(V + 1, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), nnz, V,
-                                                                       d_trp.template as<int64_t>());
-    E_LAUNCH();
-    gather_transposed_kernel<T><<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(
-        perm.template as<uint32_t>(), rowid.template as<uint32_t>(), X.vals.template as<T>(), nnz, Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>());
-    E_LAUNCH();
-    set_end_flags_kernel<<<(unsigned)cdiv(m, TB), TB, 0, st()>>>(d_rp.template as<int64_t>(), m, X.cols.template as<uint32_t>(), kLongRow);
-    E_LAUNCH();
-    set_end_flags_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(d_trp.template as<int64_t>(), V, Xt.cols.template as<uint32_t>(), kLongRow);
-    E_LAUNCH();
-    E_HIP(hipMemcpyAsync(Xt.h_rowptr.data(), d_trp.p, (V + 1) * 8, hipMemcpyDeviceToHost, st()));
-    E_HIP(hipStreamSynchronize(st()));
     have_matrix = true;
+    return 0;
+  }
+
+  // Build X^T in processing order for document blocks of 2^bs rows (see sparse_prep.hpp).
+  int ensure_xt(int bs) {
+    if (Xt.built && (Xt.block_shift == bs || nnz == 0)) return 0;
+    while ((cdiv(m, (int64_t)1 << bs) + 1) * V >= ((int64_t)1 << 32)) ++bs;
+    if (Xt.built && Xt.block_shift == bs) return 0;
+    const uint32_t n_blocks = (uint32_t)cdiv(m, (int64_t)1 << bs);
+    const size_t n = (size_t)nnz;
+    const int TB = 256;
+    DevBuf rowid, iota, key, keys_out, perm, tmp, df, flag, pos, cnt, pkey;
+    E_HIP(Xt.cols.ensure(n * 4));
+    E_HIP(Xt.vals.ensure(n * sizeof(T)));
+    E_HIP(rowid.ensure(n * 4));
+    E_HIP(iota.ensure(n * 4));
+    E_HIP(key.ensure(n * 4));
+    E_HIP(keys_out.ensure(n * 4));
+    E_HIP(perm.ensure(n * 4));
+    E_HIP(df.ensure((size_t)V * 4));
+    E_HIP(hipMemsetAsync(df.p, 0, (size_t)V * 4, st()));
+    if (X.flags_set) {  // the histogram / keys need plain column ids
+      clear_flags_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz);
+      E_LAUNCH();
+      X.flags_set = false;
+    }
+    expand_rowids_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(d_rowptr.template as<int64_t>(), m, nnz,
+                                                                   rowid.template as<uint32_t>(), iota.template as<uint32_t>());
+    E_LAUNCH();
+    col_histogram_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, df.template as<int32_t>());
+    E_LAUNCH();
+    transpose_key_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), rowid.template as<uint32_t>(),
+                                                                   df.template as<int32_t>(), nnz, V, bs, n_blocks,
+                                                                   (int32_t)kSubPiece, key.template as<uint32_t>());
+    E_LAUNCH();
+    {  // stable sort by (block, vocabulary id): documents stay ascending inside a piece
+      int bits = 1;
+      while (((int64_t)1 << bits) < ((int64_t)n_blocks + 1) * V) ++bits;
+      size_t bytes = 0;
+      E_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.template as<uint32_t>(), keys_out.template as<uint32_t>(),
+                                      iota.template as<uint32_t>(), perm.template as<uint32_t>(), n, 0u, (unsigned)bits, st()));
+      E_HIP(tmp.ensure(bytes));
+      E_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.template as<uint32_t>(), keys_out.template as<uint32_t>(),
+                                      iota.template as<uint32_t>(), perm.template as<uint32_t>(), n, 0u, (unsigned)bits, st()));
+    }
+    gather_transposed_kernel<T><<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(
+        perm.template as<uint32_t>(), rowid.template as<uint32_t>(), X.vals.template as<T>(), nnz,
+        Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>());
+    E_LAUNCH();
+    // piece starts = positions where the key changes
+    E_HIP(flag.ensure(n));
+    E_HIP(cnt.ensure(8));
+    piece_flag_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), nnz, flag.template as<uint8_t>());
+    E_LAUNCH();
+    uint32_t* d_pos = iota.template as<uint32_t>();  // iota is dead after the sort: reuse as the position list
+    {
+      size_t bytes = 0;
+      E_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flag.template as<uint8_t>(), d_pos,
+                            cnt.template as<uint32_t>(), n, st()));
+      E_HIP(tmp.ensure(bytes));
+      E_HIP(rocprim::select(tmp.p, bytes, rocprim::counting_iterator<uint32_t>(0), flag.template as<uint8_t>(), d_pos,
+                            cnt.template as<uint32_t>(), n, st()));
+    }
+    uint32_t n_pieces = 0;
+    E_HIP(hipMemcpyAsync(&n_pieces, cnt.p, 4, hipMemcpyDeviceToHost, st()));
+    E_HIP(hipStreamSynchronize(st()));
+    E_HIP(pkey.ensure((size_t)std::max<uint32_t>(n_pieces, 1) * 4));
+    gather_u32_kernel<<<(unsigned)cdiv(n_pieces, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), d_pos, n_pieces,
+                                                                     pkey.template as<uint32_t>());
+    E_LAUNCH();
+    std::vector<uint32_t> h_pos(n_pieces), h_key(n_pieces);
+    E_HIP(hipMemcpyAsync(h_pos.data(), d_pos, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st()));
+    E_HIP(hipMemcpyAsync(h_key.data(), pkey.p, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st()));
+    E_HIP(hipStreamSynchronize(st()));
+    Xt.pieces.start.resize((size_t)n_pieces + 1);
+    Xt.pieces.row.resize(n_pieces);
+    Xt.pieces.block.resize(n_pieces);
+    for (uint32_t i = 0; i < n_pieces; ++i) {
+      Xt.pieces.start[i] = h_pos[i];
+      Xt.pieces.row[i] = (int32_t)(h_key[i] % (uint64_t)V);
+      const uint32_t b = (uint32_t)(h_key[i] / (uint64_t)V);
+      Xt.pieces.block[i] = b >= n_blocks ? -1 : (int32_t)b;
+    }
+    Xt.pieces.start[n_pieces] = nnz;
+    Xt.block_shift = bs;
+    Xt.built = true;
+    Xt.flags_set = false;
+    Xt.seg_q = -1;
     return 0;
   }
 
@@ -257,22 +335,32 @@ class Engine : public ImplBase {
     return 0;
   }
 
-  int ensure_segments(StreamMat<T>& M, int64_t q) {
-    if (M.seg_q == q) return 0;
+  int ensure_segments(StreamMat<T>& M, int64_t q, int xcd_group) {
+    if (M.seg_q == q && M.seg_group == xcd_group && M.flags_set) return 0;
     HostSegments s;
-    build_segments_host(M.h_rowptr.data(), M.rows, q, kLongRow, s);
+    build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group);
+    M.seg_group = xcd_group;
     M.n_seg = s.n_seg();
-    M.n_nzrow = (int64_t)s.nzrow.size();
     M.n_empty = (int64_t)s.empty_rows.size();
     M.n_fix = (int64_t)s.fix_row.size();
     M.n_carry = s.n_carry;
     MNMF_TRY(upload(M.seg_start, s.seg_start.data(), s.seg_start.size() * 8));
+    MNMF_TRY(upload(M.seg_len, s.seg_len.data(), s.seg_len.size() * 4));
     MNMF_TRY(upload(M.seg_info, s.seg_info.data(), s.seg_info.size() * 4));
-    MNMF_TRY(upload(M.nzrow, s.nzrow.data(), s.nzrow.size() * 4));
+    MNMF_TRY(upload(M.dest, s.dest.data(), s.dest.size() * 4));
     MNMF_TRY(upload(M.empty_rows, s.empty_rows.data(), s.empty_rows.size() * 4));
     MNMF_TRY(upload(M.fix_row, s.fix_row.data(), s.fix_row.size() * 4));
     MNMF_TRY(upload(M.fix_first, s.fix_first.data(), s.fix_first.size() * 4));
     MNMF_TRY(upload(M.fix_count, s.fix_count.data(), s.fix_count.size() * 4));
+    if (!M.flags_set && !s.piece_end.empty()) {  // piece ends do not depend on q
+      DevBuf pe;
+      MNMF_TRY(upload(pe, s.piece_end.data(), s.piece_end.size() * 8));
+      set_flags_at_kernel<<<(unsigned)cdiv((int64_t)s.piece_end.size(), 256), 256, 0, st()>>>(
+          pe.template as<int64_t>(), (int64_t)s.piece_end.size(), M.cols.template as<uint32_t>());
+      E_LAUNCH();
+      E_HIP(hipStreamSynchronize(st()));
+    }
+    M.flags_set = true;
     E_HIP(hipStreamSynchronize(st()));  // host vectors die at scope exit
     M.seg_q = q;
     return 0;
@@ -286,8 +374,8 @@ class Engine : public ImplBase {
     if (waves > 0) {
       auto kern = (&M == &Xt) ? spmm_stream_kernel<T, LPR, VPL, U, 1> : spmm_stream_kernel<T, LPR, VPL, U, 0>;
       kern<<<(unsigned)cdiv(waves, 4), 256, 0, st()>>>(
-          M.seg_start.template as<int64_t>(), M.seg_info.template as<int32_t>(), M.n_seg, M.cols.template as<uint32_t>(), M.vals.template as<T>(),
-          M.nzrow.template as<int32_t>(), B, ld, out, M.carry.template as<T>());
+          M.seg_start.template as<int64_t>(), M.seg_len.template as<int32_t>(), M.seg_info.template as<int32_t>(), M.n_seg, M.cols.template as<uint32_t>(), M.vals.template as<T>(),
+          M.dest.template as<int32_t>(), B, ld, out, M.carry.template as<T>());
       E_LAUNCH();
     }
     if (M.n_fix > 0) {
@@ -307,9 +395,17 @@ class Engine : public ImplBase {
     const int vpl = nvec > 64 ? 2 : 1;
     const int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
     const int ng = kWave / lpr;
-    int64_t q = 512;
+    if (&M == &Xt) {
+      // document block = rows of W that fit about half of one XCD's 4 MiB L2
+      int bs = 8;
+      while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= tune.xt_block_bytes) ++bs;
+      MNMF_TRY(ensure_xt(bs));
+    }
+    int64_t q = (&M == &Xt) ? tune.xt_q : tune.x_q;
     while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
-    MNMF_TRY(ensure_segments(M, q));
+    const int xcd_group = (&M == &Xt && tune.xcd_affinity && Xt.pieces.block.size() == Xt.pieces.row.size() &&
+                           !Xt.pieces.row.empty()) ? 4 * ng : 0;
+    MNMF_TRY(ensure_segments(M, q, xcd_group));
     if (M.n_carry > 0) E_HIP(M.carry.ensure((size_t)M.n_carry * ld * sizeof(T)));
     if (M.n_empty > 0) {
       zero_rows_kernel<T><<<(unsigned)cdiv(M.n_empty * ld, 256), 256, 0, st()>>>(M.empty_rows.template as<int32_t>(), M.n_empty,
@@ -982,10 +1078,7 @@ int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes) {
   return MNMF_OK;
 }
 
-int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t long_row, mnmf_segments* out) {
-  if (!rowptr || !out || rows < 0) return MNMF_EINVAL;
-  HostSegments s;
-  build_segments_host(rowptr, rows, seg_nnz, long_row, s);
+static void export_segments(const HostSegments& s, mnmf_segments* out) {
   auto dup64 = [](const std::vector<int64_t>& v) {
     int64_t* p = (int64_t*)std::malloc(std::max<size_t>(v.size(), 1) * 8);
     std::memcpy(p, v.data(), v.size() * 8);
@@ -998,9 +1091,11 @@ int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, in
   };
   out->n_seg = s.n_seg();
   out->seg_start = dup64(s.seg_start);
+  out->seg_len = dup32(s.seg_len);
   out->seg_info = dup32(s.seg_info);
-  out->n_nzrow = (int64_t)s.nzrow.size();
-  out->nzrow = dup32(s.nzrow);
+  out->n_dest = (int64_t)s.dest.size();
+  out->dest = dup32(s.dest);
+  out->piece_end = dup64(s.piece_end);
   out->n_empty = (int64_t)s.empty_rows.size();
   out->empty_rows = dup32(s.empty_rows);
   out->n_fix = (int64_t)s.fix_row.size();
@@ -1008,14 +1103,41 @@ int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, in
   out->fix_first = dup32(s.fix_first);
   out->fix_count = dup32(s.fix_count);
   out->n_carry = s.n_carry;
+}
+
+int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t sub_piece, mnmf_segments* out) {
+  if (!rowptr || !out || rows < 0) return MNMF_EINVAL;
+  HostPieces pc;
+  pieces_from_rowptr(rowptr, rows, pc);
+  HostSegments s;
+  build_segments_host(pc, rows, seg_nnz, sub_piece, s);
+  export_segments(s, out);
+  return MNMF_OK;
+}
+
+int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
+                               int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece, int xcd_group,
+                               mnmf_segments* out) {
+  if (!piece_start || !out || rows < 0 || n_pieces < 0 || (n_pieces > 0 && !piece_row)) return MNMF_EINVAL;
+  HostPieces pc;
+  pc.start.assign(piece_start, piece_start + n_pieces + 1);
+  pc.row.assign(piece_row, piece_row + n_pieces);
+  if (piece_block) pc.block.assign(piece_block, piece_block + n_pieces);
+  for (int64_t i = 0; i < n_pieces; ++i)
+    if (pc.row[i] < 0 || pc.row[i] >= rows || pc.start[i + 1] <= pc.start[i]) return MNMF_EINVAL;
+  HostSegments s;
+  build_segments_host(pc, rows, seg_nnz, sub_piece, s, piece_block ? xcd_group : 0);
+  export_segments(s, out);
   return MNMF_OK;
 }
 
 void mnmf_free_segments(mnmf_segments* s) {
   if (!s) return;
   std::free(s->seg_start);
+  std::free(s->seg_len);
   std::free(s->seg_info);
-  std::free(s->nzrow);
+  std::free(s->dest);
+  std::free(s->piece_end);
   std::free(s->empty_rows);
   std::free(s->fix_row);
   std::free(s->fix_first);

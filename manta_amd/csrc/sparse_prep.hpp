@@ -1,13 +1,14 @@
-// Stream layout of a CSR matrix and the one-time preprocessing that builds it.
+// Stream layout of a sparse matrix and the one-time preprocessing that builds it.
 //
-// A "stream" is the nnz sequence of a CSR matrix (values + column ids) where the column id of
-// the LAST nnz of every ordinary row carries kEndFlag in its top bit, cut into SEGMENTS of about
-// seg_nnz consecutive nnz that begin and end on row boundaries.  Rows longer than kLongRow carry
-// no end flag; they are cut into chunk segments whose partial sums go to "carry" slots that a
-// fix-up kernel adds in a fixed order (deterministic, no atomics).  The SpMM kernel gives one
-// segment to each LPR-lane group of a wavefront, so every group streams a contiguous, equally
-// sized piece of nnz whatever the row-length distribution is (documents: ~100 nnz; vocabulary
-// rows of X^T: 1 .. m nnz).
+// A "stream" is a sequence of nnz (value + gather index) in PROCESSING order, made of PIECES: a piece is
+// a run of nnz that one lane group accumulates into one destination, and the gather index of its last
+// nnz carries kEndFlag in the top bit.  The destination of a piece is an output row (the piece is the
+// whole row) or a CARRY slot (the row is made of several pieces: rows longer than kSubPiece nnz are cut,
+// and rows of X^T are also cut at document-block boundaries so that consecutive pieces of DIFFERENT
+// vocabulary rows gather the same L2-sized block of W rows).  A fix-up kernel adds a row's carry slots in
+// a fixed order: deterministic, no atomics.  Consecutive pieces are packed into SEGMENTS of about seg_nnz
+// nnz; the SpMM kernel gives one segment to each lane group of a wavefront, so every group streams a
+// contiguous, equally sized run of nnz whatever the row-length distribution is.
 #pragma once
 #include <algorithm>
 #include <vector>
@@ -16,80 +17,152 @@
 
 namespace mnmf {
 
+constexpr int64_t kSubPiece = 512;  // longest piece (nnz)
+
+struct HostPieces {             // in processing order; piece p covers nnz [start[p], start[p+1])
+  std::vector<int64_t> start;   // n_pieces + 1
+  std::vector<int32_t> row;     // output row of the piece
+  std::vector<int32_t> block;   // optional (X^T): document block of the piece, -1 = not blocked
+};
+
 struct HostSegments {
-  std::vector<int64_t> seg_start;  // n_seg + 1
-  std::vector<int32_t> seg_info;   // >=0: index into nzrow of first row; <0: ~carry slot
-  std::vector<int32_t> nzrow, empty_rows, fix_row, fix_first, fix_count;
+  std::vector<int64_t> seg_start;  // n_seg (nnz offset of the segment's first nnz)
+  std::vector<int32_t> seg_len;    // n_seg (nnz in the segment; 0 = padding)
+  std::vector<int32_t> seg_info;   // index into dest of the segment's first piece
+  std::vector<int32_t> dest;       // per sub-piece: >= 0 output row, < 0: ~carry slot
+  std::vector<int64_t> piece_end;  // per sub-piece: position of its last nnz (gets kEndFlag)
+  std::vector<int32_t> empty_rows, fix_row, fix_first, fix_count;
   int64_t n_carry = 0;
   int64_t n_seg() const { return (int64_t)seg_info.size(); }
 };
 
-// rowptr[rows+1] (rowptr[0]==0) -> segments.  seg_nnz: target nnz per segment; long_row: rows
-// with more nnz than this are chunked into pieces of max(seg_nnz, 128).
-inline void build_segments_host(const int64_t* rp, int64_t rows, int64_t seg_nnz, int64_t long_row,
-                                HostSegments& s) {
+// Pieces of a plain CSR matrix: one per non-empty row.
+inline void pieces_from_rowptr(const int64_t* rp, int64_t rows, HostPieces& p) {
+  p.start.clear();
+  p.row.clear();
+  for (int64_t r = 0; r < rows; ++r)
+    if (rp[r + 1] > rp[r]) {
+      p.start.push_back(rp[r]);
+      p.row.push_back((int32_t)r);
+    }
+  p.start.push_back(rp[rows]);
+}
+
+// pieces (+ number of output rows) -> sub-pieces, destinations, carry table, segments.
+// xcd_group > 0 (X^T with document blocks): segments are emitted so that the workgroups that share an
+// XCD (workgroup id mod 8 under round-robin dispatch; speed only, never correctness) walk the document
+// blocks b = x, x+8, ... in order, xcd_group segments per workgroup; lists are padded with empty segments.
+inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_nnz, int64_t sub, HostSegments& s,
+                                int xcd_group = 0) {
   s = HostSegments();
   if (seg_nnz < 1) seg_nnz = 1;
-  const int64_t chunk = std::max<int64_t>(seg_nnz, 128);
-  int64_t cur = -1;
-  int32_t cur_j = 0;
+  if (sub < 1) sub = 1;
+  const int64_t np = (int64_t)pc.row.size();
+  const bool blocked = xcd_group > 0 && pc.block.size() == pc.row.size();
+  std::vector<int32_t> cnt((size_t)rows, 0);
+  for (int64_t p = 0; p < np; ++p) cnt[pc.row[p]] += (int32_t)cdiv(pc.start[p + 1] - pc.start[p], sub);
+  std::vector<int32_t> first((size_t)rows, 0);
   for (int64_t r = 0; r < rows; ++r) {
-    const int64_t a = rp[r], b = rp[r + 1], len = b - a;
-    if (len == 0) {
-      s.empty_rows.push_back((int32_t)r);
-      continue;
-    }
-    const int32_t j = (int32_t)s.nzrow.size();
-    s.nzrow.push_back((int32_t)r);
-    if (len > long_row) {
-      if (cur >= 0) {
-        s.seg_start.push_back(cur);
-        s.seg_info.push_back(cur_j);
-        cur = -1;
-      }
-      const int64_t nch = cdiv(len, chunk);
+    if (cnt[r] == 0) s.empty_rows.push_back((int32_t)r);
+    if (cnt[r] > 1) {
+      first[r] = (int32_t)s.n_carry;
       s.fix_row.push_back((int32_t)r);
       s.fix_first.push_back((int32_t)s.n_carry);
-      s.fix_count.push_back((int32_t)nch);
-      for (int64_t c = 0; c < nch; ++c) {
-        s.seg_start.push_back(a + c * chunk);
-        s.seg_info.push_back(~(int32_t)(s.n_carry++));
-      }
-    } else {
+      s.fix_count.push_back(cnt[r]);
+      s.n_carry += cnt[r];
+    }
+  }
+  std::vector<int32_t> used((size_t)rows, 0);
+  std::vector<int32_t> seg_block;
+  int64_t cur = -1;
+  int32_t cur_block = 0;
+  for (int64_t p = 0; p < np; ++p) {
+    const int32_t r = pc.row[p];
+    const int32_t blk = blocked ? pc.block[p] : 0;
+    if (blocked && cur >= 0 && blk != cur_block) {  // close the open segment at a block boundary
+      s.seg_len.push_back((int32_t)(pc.start[p] - cur));
+      cur = -1;
+    }
+    for (int64_t a = pc.start[p]; a < pc.start[p + 1]; a += sub) {
+      const int64_t b = std::min(a + sub, pc.start[p + 1]);
       if (cur < 0) {
         cur = a;
-        cur_j = j;
+        cur_block = blk;
+        s.seg_start.push_back(a);
+        s.seg_info.push_back((int32_t)s.dest.size());
+        seg_block.push_back(blk);
       }
+      s.dest.push_back(cnt[r] > 1 ? ~(first[r] + used[r]++) : r);
+      s.piece_end.push_back(b - 1);
       if (b - cur >= seg_nnz) {
-        s.seg_start.push_back(cur);
-        s.seg_info.push_back(cur_j);
+        s.seg_len.push_back((int32_t)(b - cur));
         cur = -1;
       }
     }
   }
-  if (cur >= 0) {
-    s.seg_start.push_back(cur);
-    s.seg_info.push_back(cur_j);
+  if (cur >= 0) s.seg_len.push_back((int32_t)(pc.start[np] - cur));
+  if (!blocked) return;
+  // ---- XCD-affine order
+  constexpr int kXcd = 8;
+  const int64_t ns = s.n_seg();
+  std::vector<std::vector<int64_t>> lists(kXcd);
+  std::vector<int64_t> loose;
+  for (int64_t i = 0; i < ns; ++i) {
+    if (seg_block[i] < 0) loose.push_back(i); else lists[seg_block[i] % kXcd].push_back(i);
   }
-  s.seg_start.push_back(rp[rows]);
+  // unblocked segments (short rows) top the lists up, shortest list first
+  size_t li = 0;
+  while (li < loose.size()) {
+    int best = 0;
+    for (int x = 1; x < kXcd; ++x)
+      if (lists[x].size() < lists[best].size()) best = x;
+    lists[best].push_back(loose[li++]);
+  }
+  size_t L = 0;
+  for (int x = 0; x < kXcd; ++x) L = std::max(L, lists[x].size());
+  L = (size_t)round_up((int64_t)L, xcd_group);
+  std::vector<int64_t> st2;
+  std::vector<int32_t> len2, info2;
+  st2.reserve(L * kXcd);
+  len2.reserve(L * kXcd);
+  info2.reserve(L * kXcd);
+  for (size_t i = 0; i < L; i += xcd_group)
+    for (int x = 0; x < kXcd; ++x)
+      for (int t = 0; t < xcd_group; ++t) {
+        const size_t q = i + t;
+        if (q < lists[x].size()) {
+          const int64_t id = lists[x][q];
+          st2.push_back(s.seg_start[id]);
+          len2.push_back(s.seg_len[id]);
+          info2.push_back(s.seg_info[id]);
+        } else {
+          st2.push_back(0);
+          len2.push_back(0);
+          info2.push_back(0);
+        }
+      }
+  s.seg_start.swap(st2);
+  s.seg_len.swap(len2);
+  s.seg_info.swap(info2);
 }
 
 // ---------------------------------------------------------------- device preprocessing kernels
-// rows with 1..long_row nnz: flag their last column id.
-__global__ void set_end_flags_kernel(const int64_t* __restrict__ rp, int64_t rows, uint32_t* cols,
-                                     int64_t long_row) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const int64_t a = rp[r], b = rp[r + 1];
-  if (b > a && (b - a) <= long_row) cols[b - 1] |= kEndFlag;
+__global__ void set_flags_at_kernel(const int64_t* __restrict__ pos, int64_t n, uint32_t* cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cols[pos[i]] |= kEndFlag;
 }
 
-// rowid[p] = row that owns nnz p (binary search over the row pointer).
+__global__ void clear_flags_kernel(uint32_t* cols, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cols[i] &= ~kEndFlag;
+}
+
+// rowid[p] = row that owns nnz p (binary search over the row pointer); iota[p] = p.
 __global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int64_t rows, int64_t nnz,
                                      uint32_t* __restrict__ rowid, uint32_t* __restrict__ iota) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nnz) return;
-  int64_t lo = 0, hi = rows;  // find largest r with rp[r] <= p
+  int64_t lo = 0, hi = rows;  // largest r with rp[r] <= p
   while (hi - lo > 1) {
     const int64_t mid = (lo + hi) >> 1;
     if (rp[mid] <= p) lo = mid; else hi = mid;
@@ -98,17 +171,34 @@ __global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int64_t row
   iota[p] = (uint32_t)p;
 }
 
-// ptr[j] = first index in sorted keys with key >= j, j = 0..n_keys_domain (inclusive).
-__global__ void lower_bound_ptr_kernel(const uint32_t* __restrict__ keys, int64_t nnz, int64_t domain,
-                                       int64_t* __restrict__ ptr) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > domain) return;
-  int64_t lo = 0, hi = nnz;  // first index with keys[idx] >= j
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)keys[mid] < j) lo = mid + 1; else hi = mid;
-  }
-  ptr[j] = lo;
+__global__ void col_histogram_kernel(const uint32_t* __restrict__ cols, int64_t nnz, int32_t* __restrict__ df) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nnz) atomicAdd(&df[cols[p]], 1);   // integer counts: order-independent
+}
+
+// Sort key of nnz p for the transposed stream: (document block, vocabulary id); vocabulary rows with at
+// most `long_df` nnz are not blocked (pseudo-block n_blocks), so they stay one piece.
+__global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rowid,
+                                     const int32_t* __restrict__ df, int64_t nnz, int64_t V, int block_shift,
+                                     uint32_t n_blocks, int32_t long_df, uint32_t* __restrict__ key) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  const uint32_t c = cols[p];
+  const uint32_t b = df[c] > long_df ? (rowid[p] >> block_shift) : n_blocks;
+  key[p] = (uint32_t)((uint64_t)b * (uint64_t)V + c);
+}
+
+// flag[p] = 1 where a new piece starts (key differs from the previous nnz).
+__global__ void piece_flag_kernel(const uint32_t* __restrict__ key, int64_t nnz, uint8_t* __restrict__ flag) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  flag[p] = (p == 0 || key[p] != key[p - 1]) ? 1 : 0;
+}
+
+__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t n,
+                                  uint32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
 }
 
 template <typename T>

@@ -6,7 +6,8 @@
 // wave-instruction gathers NG = 64/LPR factor rows, 16 B per lane, each row one contiguous read.
 // Each group streams its own segment; the nnz (col,val) of a segment are fetched LPR at a time with
 // one coalesced load per group (double-buffered a chunk ahead) and handed to the lanes by shuffles.
-// A row's sum is kept in registers and stored when the end flag passes: no atomics, fixed order.
+// A piece's sum is kept in registers and stored when its end flag passes (to the output row, or to a
+// carry slot when the row consists of several pieces): no atomics, fixed order.
 #pragma once
 #include "common.hpp"
 
@@ -15,8 +16,9 @@ namespace mnmf {
 // DIR only names the instantiation (0: X.B, 1: X^T.B) so profiles list the two directions apart.
 template <typename T, int LPR, int VPL, int U, int DIR>
 __global__ __launch_bounds__(256) void spmm_stream_kernel(
-    const int64_t* __restrict__ seg_start, const int32_t* __restrict__ seg_info, int64_t n_seg,
-    const uint32_t* __restrict__ cols, const T* __restrict__ vals, const int32_t* __restrict__ nzrow,
+    const int64_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+    const int32_t* __restrict__ seg_info, int64_t n_seg,
+    const uint32_t* __restrict__ cols, const T* __restrict__ vals, const int32_t* __restrict__ dest,
     const T* __restrict__ B, int ld, T* __restrict__ out, T* __restrict__ carry) {
   constexpr int VEC = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
@@ -29,14 +31,12 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(
   const int64_t seg = wave * NG + gi;
   const bool valid = seg < n_seg;
   int64_t p = 0, e = 0;
-  int info = 0;
+  int j = 0;  // index of the current piece in dest[]
   if (valid) {
     p = seg_start[seg];
-    e = seg_start[seg + 1];
-    info = seg_info[seg];
+    e = p + seg_len[seg];
+    j = seg_info[seg];
   }
-  const bool chunk = info < 0;
-  int j = chunk ? 0 : info;
   int coff[VPL];
   bool colok[VPL];
 #pragma unroll
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(
         }
         const bool endf = act[u] && (c[u] & kEndFlag);
         r[u] = 0;
-        if (endf) r[u] = nzrow[jj];
+        if (endf) r[u] = dest[jj];
         jj += endf ? 1 : 0;
       }
 #pragma unroll
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(
 #pragma unroll
           for (int x = 0; x < VEC; ++x) acc[w][x] += v[u] * b[u][w].v[x];
         if (act[u] && (c[u] & kEndFlag)) {
-          T* op = out + (int64_t)r[u] * ld;
+          // destination of the finished piece: an output row, or a carry slot of a multi-piece row
+          T* op = r[u] >= 0 ? out + (int64_t)r[u] * ld : carry + (int64_t)(~r[u]) * ld;
 #pragma unroll
           for (int w = 0; w < VPL; ++w) {
             if (colok[w]) {
@@ -127,18 +128,6 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(
     p = (p + LPR < e) ? p + LPR : e;
     cl = cn;
     vl = vn;
-  }
-  if (valid && chunk) {
-    T* cp = carry + (int64_t)(~info) * ld;
-#pragma unroll
-    for (int w = 0; w < VPL; ++w) {
-      if (colok[w]) {
-        VT o;
-#pragma unroll
-        for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
-        *reinterpret_cast<VT*>(cp + coff[w]) = o;
-      }
-    }
   }
 }
 

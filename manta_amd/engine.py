@@ -243,19 +243,31 @@ class Engine:
         return out.value
 
 
-def build_segments(rowptr, seg_nnz, long_row=512):
-    """Host-only: the segment description set_matrix builds (no GPU needed; used by CPU tests)."""
+def build_segments(rowptr=None, seg_nnz=64, sub_piece=512, *, piece_start=None, piece_row=None, piece_block=None,
+                   rows=None, xcd_group=0):
+    """Host-only: the segment description the engine builds (no GPU needed; used by CPU tests).
+    Give a CSR ``rowptr`` (one piece per non-empty row) or explicit pieces in processing order."""
     lib = _lib.load()
-    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
     s = _lib.MnmfSegments()
-    rc = lib.mnmf_build_segments(rp.ctypes.data, len(rp) - 1, int(seg_nnz), int(long_row), C.byref(s))
+    if rowptr is not None:
+        rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        rc = lib.mnmf_build_segments(rp.ctypes.data, len(rp) - 1, int(seg_nnz), int(sub_piece), C.byref(s))
+    else:
+        ps = np.ascontiguousarray(piece_start, dtype=np.int64)
+        pr = np.ascontiguousarray(piece_row, dtype=np.int32)
+        pb = None if piece_block is None else np.ascontiguousarray(piece_block, dtype=np.int32)
+        rc = lib.mnmf_build_segments_pieces(ps.ctypes.data, pr.ctypes.data, None if pb is None else pb.ctypes.data,
+                                            len(pr), int(rows), int(seg_nnz), int(sub_piece), int(xcd_group),
+                                            C.byref(s))
     if rc != 0:
         raise MnmfError(rc, "mnmf_build_segments")
     try:
         def arr(p, n, dt):
             return np.ctypeslib.as_array(p, shape=(max(int(n), 1),))[: int(n)].astype(dt).copy()
-        return dict(seg_start=arr(s.seg_start, s.n_seg + 1, np.int64), seg_info=arr(s.seg_info, s.n_seg, np.int32),
-                    nzrow=arr(s.nzrow, s.n_nzrow, np.int32), empty_rows=arr(s.empty_rows, s.n_empty, np.int32),
+        return dict(seg_start=arr(s.seg_start, s.n_seg, np.int64), seg_len=arr(s.seg_len, s.n_seg, np.int32),
+                    seg_info=arr(s.seg_info, s.n_seg, np.int32),
+                    dest=arr(s.dest, s.n_dest, np.int32), piece_end=arr(s.piece_end, s.n_dest, np.int64),
+                    empty_rows=arr(s.empty_rows, s.n_empty, np.int32),
                     fix_row=arr(s.fix_row, s.n_fix, np.int32), fix_first=arr(s.fix_first, s.n_fix, np.int32),
                     fix_count=arr(s.fix_count, s.n_fix, np.int32), n_carry=int(s.n_carry))
     finally:

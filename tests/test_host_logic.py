@@ -24,33 +24,47 @@ def test_library_exports_every_declared_symbol():
     assert lib.mnmf_version().startswith(b"mnmf")
 
 
-def _walk(rowptr, seg, long_row):
-    """Python emulation of the stream kernel's row walk: which output row every nnz lands in."""
-    rowptr = np.asarray(rowptr)
-    nnz = int(rowptr[-1])
-    rows = len(rowptr) - 1
-    lens = np.diff(rowptr)
+def _walk(seg, nnz):
+    """Python emulation of the stream kernel: which destination every nnz is accumulated into.
+    Returns dest_of_nnz (>=0 row, <0 ~carry slot)."""
     endflag = np.zeros(nnz, bool)
-    for r in range(rows):
-        if 0 < lens[r] <= long_row:
-            endflag[rowptr[r + 1] - 1] = True
-    dest = np.full(nnz, -1, np.int64)       # row id, or -(carry+2)
+    endflag[seg["piece_end"]] = True
+    out = np.full(nnz, np.iinfo(np.int64).min, np.int64)
     for s in range(len(seg["seg_info"])):
-        a, b = seg["seg_start"][s], seg["seg_start"][s + 1]
-        info = seg["seg_info"][s]
-        if info < 0:
-            assert not endflag[a:b].any()
-            dest[a:b] = -(~info) - 2
-        else:
-            j = info
-            start = a
-            for p in range(a, b):
-                if endflag[p]:
-                    dest[start:p + 1] = seg["nzrow"][j]
-                    j += 1
-                    start = p + 1
-            assert start == b, "an ordinary segment must end on a row boundary"
-    return dest
+        a, b = seg["seg_start"][s], seg["seg_start"][s] + seg["seg_len"][s]
+        j = seg["seg_info"][s]
+        start = a
+        for p in range(a, b):
+            if endflag[p]:
+                out[start:p + 1] = seg["dest"][j]
+                j += 1
+                start = p + 1
+        assert start == b, "a segment must end on a piece boundary"
+    return out
+
+
+def _check_cover(seg, truth_rows, n_rows, sub):
+    """Every nnz lands in its row, directly or through that row's carry slots (in slot order)."""
+    nnz = len(truth_rows)
+    d = _walk(seg, nnz)
+    direct = d >= 0
+    assert np.array_equal(d[direct], truth_rows[direct])
+    slot_row = np.full(seg["n_carry"], -1, np.int64)
+    for r, first, cnt in zip(seg["fix_row"], seg["fix_first"], seg["fix_count"]):
+        assert cnt >= 2
+        slot_row[first:first + cnt] = r
+    assert (slot_row >= 0).all()
+    slots = ~d[~direct]
+    assert np.array_equal(slot_row[slots], truth_rows[~direct])
+    assert sorted(set(slots.tolist())) == list(range(seg["n_carry"])), "every carry slot is written"
+    # a row is either direct (one piece) or carried, never both
+    assert not set(truth_rows[direct].tolist()) & set(seg["fix_row"].tolist())
+    # sub-pieces are never longer than `sub`
+    ends = np.sort(seg["piece_end"])
+    assert np.all(np.diff(np.concatenate([[-1], ends])) <= sub)
+    present = np.zeros(n_rows, bool)
+    present[truth_rows] = True
+    assert sorted(seg["empty_rows"].tolist()) == np.nonzero(~present)[0].tolist()
 
 
 @pytest.mark.parametrize("seg_nnz", [1, 32, 64, 512])
@@ -61,32 +75,67 @@ def test_segments_cover_every_nnz_once(seg_nnz):
     lens = rng.poisson(20, 400)
     lens[[0, 5, 6, 399]] = 0                 # empty rows incl. first and last
     lens[[10, 200]] = [2000, 513]            # long rows
-    lens[11] = 512                           # exactly at the threshold: not long
+    lens[11] = 512                           # exactly at the threshold: one piece
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     seg = build_segments(rowptr, seg_nnz, 512)
-    assert seg["seg_start"][0] == 0 and seg["seg_start"][-1] == rowptr[-1]
+    assert seg["seg_start"][0] == 0 and seg["seg_len"].sum() == rowptr[-1]
     assert np.all(np.diff(seg["seg_start"]) > 0)
-    assert sorted(seg["empty_rows"].tolist()) == np.nonzero(lens == 0)[0].tolist()
-    assert seg["nzrow"].tolist() == np.nonzero(lens > 0)[0].tolist()
     assert sorted(seg["fix_row"].tolist()) == [10, 200]
-    dest = _walk(rowptr, seg, 512)
-    truth = np.repeat(np.arange(400), lens)
-    normal = dest >= 0
-    assert np.array_equal(dest[normal], truth[normal])
-    # chunked rows: their carry slots, in order, cover exactly the row's nnz
-    for r, first, cnt in zip(seg["fix_row"], seg["fix_first"], seg["fix_count"]):
-        slots = -(dest[rowptr[r]:rowptr[r + 1]]) - 2
-        assert slots.min() == first and slots.max() == first + cnt - 1
-        assert np.all(np.diff(slots) >= 0)
-    assert seg["n_carry"] == int(seg["fix_count"].sum())
-    assert not normal[rowptr[10]:rowptr[11]].any() and normal[rowptr[11]:rowptr[12]].all()
+    _check_cover(seg, np.repeat(np.arange(400), lens), 400, 512)
+
+
+def test_segments_blocked_pieces():
+    """Document-blocked X^T: a vocabulary row appears as several pieces (one per block), interleaved
+    with pieces of other rows; short rows come last as single pieces."""
+    from manta_amd.engine import build_segments
+
+    rng = np.random.RandomState(7)
+    n_rows, n_blocks = 50, 6
+    n_blocks = 19
+    rows, lens, blocks = [], [], []
+    for b in range(n_blocks):
+        for r in range(0, 30):               # "long" rows: present in most blocks
+            if rng.rand() < 0.8:
+                rows.append(r)
+                lens.append(int(rng.randint(1, 1400)))
+                blocks.append(b)
+    for r in range(30, 48):                  # short rows: one piece each; rows 48, 49 empty
+        rows.append(r)
+        lens.append(int(rng.randint(1, 40)))
+        blocks.append(-1)
+    start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for q, group in ((32, 0), (512, 0), (64, 16), (512, 4)):
+        seg = build_segments(piece_start=start, piece_row=np.array(rows), piece_block=np.array(blocks), rows=n_rows,
+                             seg_nnz=q, sub_piece=512, xcd_group=group)
+        _check_cover(seg, np.repeat(np.array(rows), lens), n_rows, 512)
+        if group:
+            # XCD-affine order: workgroup g holds `group` segments, all of blocks congruent to g mod 8
+            nb_of_nnz = np.repeat(np.array(blocks), lens)
+            assert len(seg["seg_len"]) % (8 * group) == 0
+            for s_i in range(len(seg["seg_len"])):
+                if seg["seg_len"][s_i] == 0:
+                    continue
+                blk = nb_of_nnz[seg["seg_start"][s_i]]
+                if blk >= 0:
+                    assert blk % 8 == (s_i // group) % 8
+            # inside one XCD's list the blocks come in ascending order
+            for x in range(8):
+                ids = [i for i in range(len(seg["seg_len"])) if (i // group) % 8 == x and seg["seg_len"][i] > 0]
+                bl = [nb_of_nnz[seg["seg_start"][i]] for i in ids]
+                bl = [b for b in bl if b >= 0]
+                assert bl == sorted(bl)
+        # carry slots of a row are numbered in processing order
+        d = _walk(seg, int(start[-1]))
+        for r, first, cnt in zip(seg["fix_row"], seg["fix_first"], seg["fix_count"]):
+            sl = ~d[(np.repeat(np.array(rows), lens) == r)]
+            assert np.all(np.diff(sl) >= 0) and sl.min() == first and sl.max() == first + cnt - 1
 
 
 def test_segments_degenerate():
     from manta_amd.engine import build_segments
 
     seg = build_segments(np.zeros(6, np.int64), 64)      # all rows empty
-    assert len(seg["seg_info"]) == 0 and seg["seg_start"].tolist() == [0] and len(seg["empty_rows"]) == 5
+    assert len(seg["seg_info"]) == 0 and len(seg["empty_rows"]) == 5
     seg = build_segments(np.array([0], np.int64), 64)    # no rows
     assert len(seg["seg_info"]) == 0
 
