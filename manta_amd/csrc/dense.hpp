@@ -79,15 +79,26 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__
   }
 }
 
-// out[e] = sum over chunks of slab[chunk][e] in chunk order (deterministic).
+// out[e] = sum over chunks of slab[chunk][e], in a fixed order (deterministic): 16 threads per element
+// take chunks c = t, t+16, ... each, then their 16 partial sums are added in lane order.
+// block 256 = 16 elements x 16 chunk lanes.
 template <typename T>
-__global__ void slab_reduce_kernel(const T* __restrict__ slab, int64_t n_chunks, int64_t elems,
-                                   T* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const T* __restrict__ slab, int64_t n_chunks,
+                                                          int64_t elems, T* __restrict__ out) {
+  __shared__ T part[16][17];
+  const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 16 + el;
   T s = T(0);
-  for (int64_t c = 0; c < n_chunks; ++c) s += slab[c * elems + e];
-  out[e] = s;
+  if (e < elems)
+    for (int64_t c = cl; c < n_chunks; c += 16) s += slab[c * elems + e];
+  part[cl][el] = s;
+  __syncthreads();
+  if (cl == 0 && e < elems) {
+    T t = T(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][el];
+    out[e] = t;
+  }
 }
 
 // -------------------------------------------------------------- rows x (k x k) products + MU update

@@ -74,12 +74,14 @@ struct Tune {
   int64_t xt_q = 512;                 // target nnz per segment, X^T stream
   int64_t xt_block_bytes = 2 << 20;   // bytes of W rows per document block of X^T
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
+  int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
     x_q = geti("MNMF_X_Q", x_q);
     xt_q = geti("MNMF_XT_Q", xt_q);
     xt_block_bytes = geti("MNMF_XT_BLOCK_BYTES", xt_block_bytes);
     xcd_affinity = (int)geti("MNMF_XCD_AFFINITY", xcd_affinity);
+    ld_align = (int)geti("MNMF_LD_ALIGN", ld_align);
   }
 };
 
@@ -151,7 +153,12 @@ class Engine : public ImplBase {
   double phase_ms[PhaseTimer::kMaxPhases] = {0};
 
   hipStream_t st() const { return ctx->stream; }
-  static int ld_of(int k) { return (int)round_up(k, 4); }
+  // leading dimension of every factor matrix: a multiple of 4 elements; rows of more than 32 elements
+  // are padded to whole 64-byte multiples (tune.ld_align elements) so a gathered row starts line-aligned.
+  int ld_of(int k) const {
+    const int a = (k > 32 && tune.ld_align > 4) ? tune.ld_align : 4;
+    return (int)round_up(k, a);
+  }
 
   int fail(int code, const std::string& msg) {
     ctx->fail(code, msg);
@@ -439,7 +446,7 @@ class Engine : public ImplBase {
     else
       gram_partial_kernel<T, false><<<grid, 256, 0, st()>>>(A, A2, B, B2, rows, ld, rpc, slab.template as<T>());
     E_LAUNCH();
-    slab_reduce_kernel<T><<<(unsigned)cdiv(elems, 256), 256, 0, st()>>>(slab.template as<T>(), chunks, elems, out);
+    slab_reduce_kernel<T><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(slab.template as<T>(), chunks, elems, out);
     E_LAUNCH();
     return 0;
   }
