@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmnmf.so")
+LIB_PATH = os.environ.get("MNMF_LIB") or os.path.join(HERE, "libmnmf.so")
 
 MNMF_F32, MNMF_F64 = 0, 1
 STATUS = {0: "MNMF_OK", -1: "MNMF_EINVAL", -2: "MNMF_EHIP", -3: "MNMF_ECOMM", -4: "MNMF_ENAN", -5: "MNMF_ESTATE"}

@@ -240,31 +240,34 @@ __global__ void pad_sq_kernel(const T* __restrict__ in, int k, int ld, T* __rest
 
 // ------------------------------------------------------------------------------- layout conversion
 // rows x k (dense, leading dim k) -> rows x ld zero padded.
+// `map` (may be null): internal row id of user row r (the vocabulary renumbering).
 template <typename T>
-__global__ void pad_rows_kernel(const T* __restrict__ in, int64_t rows, int k, int ld, T* __restrict__ out) {
+__global__ void pad_rows_kernel(const T* __restrict__ in, int64_t rows, int k, int ld, T* __restrict__ out,
+                                const int32_t* __restrict__ map = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * ld) return;
   const int64_t r = i / ld;
   const int c = (int)(i % ld);
-  out[i] = c < k ? in[r * k + c] : T(0);
+  const int64_t ro = map ? map[r] : r;
+  out[ro * ld + c] = c < k ? in[r * k + c] : T(0);
 }
 
 // rows x ld -> rows x k, entries below thr set to 0 (thr <= 0: plain copy) (nmf_basic.py:86-87).
 template <typename T>
 __global__ void unpad_rows_kernel(const T* __restrict__ in, int64_t rows, int k, int ld, T thr,
-                                  T* __restrict__ out) {
+                                  T* __restrict__ out, const int32_t* __restrict__ map = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * k) return;
   const int64_t r = i / k;
   const int c = (int)(i % k);
-  const T v = in[r * ld + c];
+  const T v = in[(map ? (int64_t)map[r] : r) * ld + c];
   out[i] = (v < thr) ? T(0) : v;
 }
 
 // H (k x V row-major) -> Ht (V x ld, zero padded), 32 x 32 tiles through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_in_kernel(const T* __restrict__ H, int k, int64_t V, int ld,
-                                                           T* __restrict__ Ht) {
+                                                           T* __restrict__ Ht, const int32_t* __restrict__ map) {
   __shared__ T tile[32][33];
   const int64_t v0 = (int64_t)blockIdx.x * 32;
   const int c0 = blockIdx.y * 32;
@@ -278,14 +281,14 @@ __global__ __launch_bounds__(256) void transpose_in_kernel(const T* __restrict__
   for (int i = ty; i < 32; i += 8) {
     const int64_t v = v0 + i;
     const int c = c0 + tx;
-    if (v < V && c < ld) Ht[v * ld + c] = tile[tx][i];
+    if (v < V && c < ld) Ht[(map ? (int64_t)map[v] : v) * ld + c] = tile[tx][i];
   }
 }
 
 // Ht (V x ld) -> H (k x V), thresholded.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_out_kernel(const T* __restrict__ Ht, int k, int64_t V, int ld,
-                                                            T thr, T* __restrict__ H) {
+                                                            T thr, T* __restrict__ H, const int32_t* __restrict__ map) {
   __shared__ T tile[32][33];
   const int64_t v0 = (int64_t)blockIdx.x * 32;
   const int c0 = blockIdx.y * 32;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const T* __restrict_
   for (int i = ty; i < 32; i += 8) {
     const int64_t v = v0 + i;
     const int c = c0 + tx;
-    tile[i][tx] = (v < V && c < ld) ? Ht[v * ld + c] : T(0);
+    tile[i][tx] = (v < V && c < ld) ? Ht[(map ? (int64_t)map[v] : v) * ld + c] : T(0);
   }
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {

@@ -31,6 +31,7 @@ struct ImplBase {
   virtual int k_update(int64_t rows, int k, const void* A, const void* num, const void* G, const void* G2,
                        double eps, int sqrt_mode, void* out) = 0;
   virtual int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) = 0;
+  virtual int hook_changed() = 0;
 };
 
 struct mnmf_ctx {
@@ -75,6 +76,9 @@ struct Tune {
   int64_t xt_block_bytes = 2 << 20;   // bytes of W rows per document block of X^T
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
+  int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
+  int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
+  int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
     x_q = geti("MNMF_X_Q", x_q);
@@ -82,6 +86,9 @@ struct Tune {
     xt_block_bytes = geti("MNMF_XT_BLOCK_BYTES", xt_block_bytes);
     xcd_affinity = (int)geti("MNMF_XCD_AFFINITY", xcd_affinity);
     ld_align = (int)geti("MNMF_LD_ALIGN", ld_align);
+    permute_vocab = (int)geti("MNMF_PERMUTE_VOCAB", permute_vocab);
+    hot_lds_bytes = geti("MNMF_HOT_LDS_BYTES", hot_lds_bytes);
+    hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
   }
 };
 
@@ -120,7 +127,7 @@ struct StreamMat {
   bool built = false, flags_set = false;
   int block_shift = -1;                      // X^T only: log2(documents per block)
   // segment description for the current seg_q
-  int64_t seg_q = -1, n_seg = 0, n_empty = 0, n_fix = 0, n_carry = 0;
+  int64_t seg_q = -1, n_seg = 0, n_dest = 0, n_empty = 0, n_fix = 0, n_carry = 0;
   int seg_group = -1;
   DevBuf seg_start, seg_len, seg_info, dest, empty_rows, fix_row, fix_first, fix_count, carry;
 };
@@ -134,7 +141,10 @@ inline int pow2_ceil(int x) {
 template <typename T>
 class Engine : public ImplBase {
  public:
-  explicit Engine(mnmf_ctx* c) : ctx(c) {}
+  explicit Engine(mnmf_ctx* c) : ctx(c) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) n_cus = v;
+  }
   ~Engine() override {
     if (h_pinned) (void)hipHostFree(h_pinned);
   }
@@ -146,6 +156,11 @@ class Engine : public ImplBase {
   StreamMat<T> X, Xt;
   std::vector<int64_t> h_rowptr;
   DevBuf d_rowptr;
+  // vocabulary renumbering by descending document frequency (identical on every rank)
+  bool prepared = false;
+  DevBuf d_newid, d_order;   // int32 newid[old], uint32 order[new]
+  const int32_t* vmap() const { return (prepared && tune.permute_vocab && nnz > 0) ? d_newid.template as<int32_t>() : nullptr; }
+  int n_cus = 256;
   // solver workspaces
   DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD;
   double* h_pinned = nullptr;
@@ -208,6 +223,7 @@ class Engine : public ImplBase {
       if (h_rowptr[r + 1] < h_rowptr[r]) return fail(MNMF_EINVAL, "set_matrix: rowptr not monotone");
     X = StreamMat<T>();
     Xt = StreamMat<T>();
+    prepared = false;
     X.rows = m;
     X.tab_rows = V;
     X.nnz = nnz;
@@ -248,6 +264,70 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  int clear_x_flags() {
+    if (X.flags_set && nnz > 0) {
+      clear_flags_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, st()>>>(X.cols.template as<uint32_t>(), nnz);
+      E_LAUNCH();
+    }
+    X.flags_set = false;
+    return 0;
+  }
+
+  // Renumber the vocabulary by descending document frequency (ties: ascending id), so that the rows of
+  // H^T that are gathered most are the first rows.  df is summed over ranks through the all-reduce hook
+  // before sorting, so every rank derives the same numbering (H^T is replicated and all-reduced).
+  int ensure_prepared() {
+    if (prepared) return 0;
+    prepared = true;
+    if (!tune.permute_vocab || nnz == 0) return 0;
+    const int TB = 256;
+    DevBuf df, key, key_out, iota, tmp;
+    E_HIP(df.ensure((size_t)V * 4));
+    E_HIP(key.ensure((size_t)V * sizeof(T)));
+    E_HIP(key_out.ensure((size_t)V * sizeof(T)));
+    E_HIP(iota.ensure((size_t)V * 4));
+    E_HIP(d_newid.ensure((size_t)V * 4));
+    E_HIP(d_order.ensure((size_t)V * 4));
+    MNMF_TRY(clear_x_flags());
+    E_HIP(hipMemsetAsync(df.p, 0, (size_t)V * 4, st()));
+    col_histogram_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, df.template as<int32_t>());
+    E_LAUNCH();
+    df_to_key_kernel<T><<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(df.template as<int32_t>(), V, key.template as<T>(), iota.template as<uint32_t>());
+    E_LAUNCH();
+    MNMF_TRY(allreduce(key.template as<T>(), V));
+    size_t bytes = 0;
+    E_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, key.template as<T>(), key_out.template as<T>(), iota.template as<uint32_t>(),
+                                         d_order.template as<uint32_t>(), (size_t)V, 0u, (unsigned)(8 * sizeof(T)), st()));
+    E_HIP(tmp.ensure(bytes));
+    E_HIP(rocprim::radix_sort_pairs_desc(tmp.p, bytes, key.template as<T>(), key_out.template as<T>(), iota.template as<uint32_t>(),
+                                         d_order.template as<uint32_t>(), (size_t)V, 0u, (unsigned)(8 * sizeof(T)), st()));
+    invert_perm_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(d_order.template as<uint32_t>(), V, d_newid.template as<int32_t>());
+    E_LAUNCH();
+    remap_cols_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, d_newid.template as<int32_t>());
+    E_LAUNCH();
+    E_HIP(hipStreamSynchronize(st()));
+    Xt.built = false;
+    Xt.seg_q = -1;
+    return 0;
+  }
+
+  // The all-reduce hook (hence the rank count) changed: the renumbering must be derived again.
+  int hook_changed() override {
+    if (!have_matrix || !prepared) return 0;
+    E_HIP(hipSetDevice(ctx->device));
+    if (tune.permute_vocab && nnz > 0) {
+      MNMF_TRY(clear_x_flags());
+      // back to the caller's ids: order[new] = old, as int32 map
+      remap_cols_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, d_order.template as<int32_t>());
+      E_LAUNCH();
+      E_HIP(hipStreamSynchronize(st()));
+    }
+    prepared = false;
+    Xt.built = false;
+    Xt.seg_q = -1;
+    return 0;
+  }
+
   // Build X^T in processing order for document blocks of 2^bs rows (see sparse_prep.hpp).
   int ensure_xt(int bs) {
     if (Xt.built && (Xt.block_shift == bs || nnz == 0)) return 0;
@@ -266,11 +346,7 @@ class Engine : public ImplBase {
     E_HIP(perm.ensure(n * 4));
     E_HIP(df.ensure((size_t)V * 4));
     E_HIP(hipMemsetAsync(df.p, 0, (size_t)V * 4, st()));
-    if (X.flags_set) {  // the histogram / keys need plain column ids
-      clear_flags_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz);
-      E_LAUNCH();
-      X.flags_set = false;
-    }
+    MNMF_TRY(clear_x_flags());  // the histogram / keys need plain column ids
     expand_rowids_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(d_rowptr.template as<int64_t>(), m, nnz,
                                                                    rowid.template as<uint32_t>(), iota.template as<uint32_t>());
     E_LAUNCH();
@@ -348,6 +424,7 @@ class Engine : public ImplBase {
     build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group);
     M.seg_group = xcd_group;
     M.n_seg = s.n_seg();
+    M.n_dest = (int64_t)s.dest.size();
     M.n_empty = (int64_t)s.empty_rows.size();
     M.n_fix = (int64_t)s.fix_row.size();
     M.n_carry = s.n_carry;
@@ -374,15 +451,32 @@ class Engine : public ImplBase {
   }
 
   // ------------------------------------------------------------------ kernels
-  template <int LPR, int VPL, int U>
-  int spmm_launch(StreamMat<T>& M, const T* B, int ld, T* out) {
+  template <int LPR, int VPL>
+  int spmm_launch(StreamMat<T>& M, const T* B, int ld, T* out, int hot, int lds_ld) {
     constexpr int NG = kWave / LPR;
     const int64_t waves = cdiv(M.n_seg, NG);
-    if (waves > 0) {
-      auto kern = (&M == &Xt) ? spmm_stream_kernel<T, LPR, VPL, U, 1> : spmm_stream_kernel<T, LPR, VPL, U, 0>;
-      kern<<<(unsigned)cdiv(waves, 4), 256, 0, st()>>>(
-          M.seg_start.template as<int64_t>(), M.seg_len.template as<int32_t>(), M.seg_info.template as<int32_t>(), M.n_seg, M.cols.template as<uint32_t>(), M.vals.template as<T>(),
-          M.dest.template as<int32_t>(), B, ld, out, M.carry.template as<T>());
+    const size_t tab_bytes = (size_t)M.tab_rows * ld * sizeof(T);
+    const bool wide = M.tab_rows >= ((int64_t)1 << 24) || tab_bytes >= ((size_t)1 << 32) ||
+                      (size_t)ld * sizeof(T) >= ((size_t)1 << 24);
+    SpmmArgs<T> a{M.seg_start.template as<int64_t>(), M.seg_len.template as<int32_t>(), M.seg_info.template as<int32_t>(), M.n_seg,
+                  M.cols.template as<uint32_t>(), M.vals.template as<T>(), M.dest.template as<int32_t>(), M.n_dest,
+                  B, ld, out, M.carry.template as<T>(), hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes};
+    if (waves > 0 && hot > 0 && !wide) {
+      auto kern = spmm_stream_kernel<T, LPR, VPL, 0, true, false>;
+      const size_t lds_bytes = (size_t)hot * lds_ld * sizeof(T);
+      E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      kern<<<(unsigned)n_cus, 1024, lds_bytes, st()>>>(a);
+      E_LAUNCH();
+    } else if (waves > 0) {
+      a.hot_rows = 0;
+      const unsigned grid = (unsigned)cdiv(waves, 4);
+      if (&M == &Xt) {
+        if (wide) spmm_stream_kernel<T, LPR, VPL, 1, false, true><<<grid, 256, 0, st()>>>(a);
+        else spmm_stream_kernel<T, LPR, VPL, 1, false, false><<<grid, 256, 0, st()>>>(a);
+      } else {
+        if (wide) spmm_stream_kernel<T, LPR, VPL, 0, false, true><<<grid, 256, 0, st()>>>(a);
+        else spmm_stream_kernel<T, LPR, VPL, 0, false, false><<<grid, 256, 0, st()>>>(a);
+      }
       E_LAUNCH();
     }
     if (M.n_fix > 0) {
@@ -402,6 +496,7 @@ class Engine : public ImplBase {
     const int vpl = nvec > 64 ? 2 : 1;
     const int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
     const int ng = kWave / lpr;
+    MNMF_TRY(ensure_prepared());
     if (&M == &Xt) {
       // document block = rows of W that fit about half of one XCD's 4 MiB L2
       int bs = 8;
@@ -419,13 +514,21 @@ class Engine : public ImplBase {
                                                                                 ld, out);
       E_LAUNCH();
     }
-    if (vpl == 2) return spmm_launch<64, 2, 4>(M, B, ld, out);
+    // X direction: stage the most frequent rows of the (renumbered) factor in LDS
+    int hot = 0;
+    const int lds_ld = ld + VEC;
+    if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= tune.hot_min_nnz &&
+        (int64_t)M.tab_rows * ld * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
+      hot = (int)std::min<int64_t>(M.tab_rows, tune.hot_lds_bytes / ((int64_t)lds_ld * (int64_t)sizeof(T)));
+      if (hot < 16) hot = 0;
+    }
+    if (vpl == 2) return spmm_launch<64, 2>(M, B, ld, out, hot, lds_ld);
     switch (lpr) {
-      case 4: return spmm_launch<4, 1, 4>(M, B, ld, out);
-      case 8: return spmm_launch<8, 1, 8>(M, B, ld, out);
-      case 16: return spmm_launch<16, 1, 8>(M, B, ld, out);
-      case 32: return spmm_launch<32, 1, 8>(M, B, ld, out);
-      default: return spmm_launch<64, 1, 8>(M, B, ld, out);
+      case 4: return spmm_launch<4, 1>(M, B, ld, out, hot, lds_ld);
+      case 8: return spmm_launch<8, 1>(M, B, ld, out, hot, lds_ld);
+      case 16: return spmm_launch<16, 1>(M, B, ld, out, hot, lds_ld);
+      case 32: return spmm_launch<32, 1>(M, B, ld, out, hot, lds_ld);
+      default: return spmm_launch<64, 1>(M, B, ld, out, hot, lds_ld);
     }
   }
 
@@ -501,7 +604,8 @@ class Engine : public ImplBase {
   }
   int load_H(const void* H, int k, int ld, T* dst) {
     dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(ld, 32));
-    transpose_in_kernel<T><<<grid, 256, 0, st()>>>((const T*)H, k, V, ld, dst);
+    MNMF_TRY(ensure_prepared());
+    transpose_in_kernel<T><<<grid, 256, 0, st()>>>((const T*)H, k, V, ld, dst, vmap());
     E_LAUNCH();
     return 0;
   }
@@ -513,7 +617,7 @@ class Engine : public ImplBase {
   }
   int store_H(const T* src, int k, int ld, double thr, void* H) {
     dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(ld, 32));
-    transpose_out_kernel<T><<<grid, 256, 0, st()>>>(src, k, V, ld, (T)thr, (T*)H);
+    transpose_out_kernel<T><<<grid, 256, 0, st()>>>(src, k, V, ld, (T)thr, (T*)H, vmap());
     E_LAUNCH();
     return 0;
   }
@@ -924,11 +1028,15 @@ class Engine : public ImplBase {
     StreamMat<T>& M = transpose ? Xt : X;
     E_HIP(tmpA.ensure((size_t)std::max<int64_t>(M.tab_rows, 1) * ld * sizeof(T)));
     E_HIP(tmpB.ensure((size_t)std::max<int64_t>(M.rows, 1) * ld * sizeof(T)));
-    pad_rows_kernel<T><<<(unsigned)cdiv(std::max<int64_t>(M.tab_rows * ld, 1), 256), 256, 0, st()>>>((const T*)B, M.tab_rows, k, ld, tmpA.template as<T>());
+    MNMF_TRY(ensure_prepared());
+    // vocabulary-indexed operands (B for X.B, the result for X^T.B) go through the renumbering
+    pad_rows_kernel<T><<<(unsigned)cdiv(std::max<int64_t>(M.tab_rows * ld, 1), 256), 256, 0, st()>>>(
+        (const T*)B, M.tab_rows, k, ld, tmpA.template as<T>(), transpose ? nullptr : vmap());
     E_LAUNCH();
     MNMF_TRY(spmm(M, tmpA.template as<T>(), ld, tmpB.template as<T>()));
     if (M.rows * k > 0) {
-      unpad_rows_kernel<T><<<(unsigned)cdiv(M.rows * k, 256), 256, 0, st()>>>(tmpB.template as<T>(), M.rows, k, ld, (T)-1, (T*)out);
+      unpad_rows_kernel<T><<<(unsigned)cdiv(M.rows * k, 256), 256, 0, st()>>>(tmpB.template as<T>(), M.rows, k, ld, (T)-1, (T*)out,
+                                                                             transpose ? vmap() : nullptr);
       E_LAUNCH();
     }
     E_HIP(hipStreamSynchronize(st()));
@@ -1037,7 +1145,7 @@ int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ra
   ctx->ar = fn;
   ctx->ar_user = user;
   ctx->n_ranks = n_ranks > 0 ? n_ranks : 1;
-  return MNMF_OK;
+  return ctx->impl->hook_changed();
 }
 
 int mnmf_set_matrix(mnmf_ctx* ctx, int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,

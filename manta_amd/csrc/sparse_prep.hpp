@@ -195,6 +195,27 @@ __global__ void piece_flag_kernel(const uint32_t* __restrict__ key, int64_t nnz,
   flag[p] = (p == 0 || key[p] != key[p - 1]) ? 1 : 0;
 }
 
+// order[i] = old id of the row with new id i  ->  newid[old] = i
+__global__ void invert_perm_kernel(const uint32_t* __restrict__ order, int64_t n, int32_t* __restrict__ newid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) newid[order[i]] = (int32_t)i;
+}
+
+// cols[p] = map[cols[p]]  (end flags must be clear)
+__global__ void remap_cols_kernel(uint32_t* cols, int64_t nnz, const int32_t* __restrict__ map) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nnz) cols[p] = (uint32_t)map[cols[p]];
+}
+
+template <typename T>
+__global__ void df_to_key_kernel(const int32_t* __restrict__ df, int64_t n, T* __restrict__ key, uint32_t* __restrict__ iota) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    key[i] = (T)df[i];
+    iota[i] = (uint32_t)i;
+  }
+}
+
 __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t n,
                                   uint32_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -11,123 +11,224 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef MNMF_ABLATE
+#define MNMF_ABLATE 0
+#endif
+
 namespace mnmf {
 
+template <typename T>
+struct SpmmArgs {
+  const int64_t* seg_start;  // [n_seg] first nnz of the segment
+  const int32_t* seg_len;    // [n_seg]
+  const int32_t* seg_info;   // [n_seg] index into dest of the segment's first piece
+  int64_t n_seg;
+  const uint32_t* cols;      // gather index, top bit = end of piece
+  const T* vals;
+  const int32_t* dest;       // per piece: >= 0 output row, < 0 ~carry slot
+  int64_t n_dest;
+  const T* B;                // gather table, tab_rows x ld
+  int ld;
+  T* out;
+  T* carry;
+  int hot_rows;              // HOT: first rows of B staged in LDS
+  int lds_ld;                // HOT: LDS row stride (elements)
+  uint32_t tab_bytes;        // bytes of B (non-WIDE: < 4 GiB)
+};
+
+// The inner loop is written for a low instruction count per nnz (the gather of 16 B per lane is the
+// only memory instruction per step): 32-bit offsets, one v_mad_u32_u24 per gather address (it ignores
+// the flag bit), bounds-checked buffer loads, (col,val,dest) prefetched a chunk ahead with coalesced
+// loads and handed out by ds_bpermute, and a wave-uniform branch around the rare end-of-piece work.
+//
 // DIR only names the instantiation (0: X.B, 1: X^T.B) so profiles list the two directions apart.
-template <typename T, int LPR, int VPL, int U, int DIR>
-__global__ __launch_bounds__(256) void spmm_stream_kernel(
-    const int64_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
-    const int32_t* __restrict__ seg_info, int64_t n_seg,
-    const uint32_t* __restrict__ cols, const T* __restrict__ vals, const int32_t* __restrict__ dest,
-    const T* __restrict__ B, int ld, T* __restrict__ out, T* __restrict__ carry) {
+// WIDE: tables with >= 2^24 rows or >= 4 GiB use 64-bit addressing and plain global loads.
+// HOT: persistent launch (one 1024-thread workgroup per CU, grid-stride over wave slots) that first
+// stages the first `hot_rows` rows of B -- the most frequent vocabulary rows after the engine's
+// document-frequency renumbering -- in LDS (row stride lds_ld, 16 B of padding against bank conflicts).
+// Hot rows are read from LDS; only the lanes of cold rows issue the buffer load (an out-of-range offset
+// instead of the exec mask was measured to cost the full vector-memory time).
+template <typename T, int LPR, int VPL, int DIR, bool HOT, bool WIDE>
+__global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
   constexpr int VEC = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
+  using U4 = __attribute__((ext_vector_type(4))) unsigned int;
   constexpr int NG = kWave / LPR;
-  static_assert(LPR % U == 0, "U must divide LPR");
+  constexpr int CH = LPR < 16 ? 16 : LPR;  // steps per chunk
+  constexpr int EPL = CH / LPR;            // chunk elements held per lane
+  constexpr int U = VPL == 2 ? 4 : 8;      // gathers in flight per batch
+  static_assert(CH % U == 0, "U must divide CH");
+  extern __shared__ __align__(16) unsigned char mnmf_smem[];
+  T* lds = reinterpret_cast<T*>(mnmf_smem);
+  const int ld = a.ld;
+  if (HOT) {
+    const int nvr = ld / VEC;
+    const int total = a.hot_rows * nvr;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int r = i / nvr, c = (i - r * nvr) * VEC;
+      *reinterpret_cast<VT*>(lds + (size_t)r * a.lds_ld + c) = *reinterpret_cast<const VT*>(a.B + (size_t)r * ld + c);
+    }
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int gi = lane / LPR, li = lane % LPR;
   const int gbase = gi * LPR;
-  const int64_t seg = wave * NG + gi;
-  const bool valid = seg < n_seg;
-  int64_t p = 0, e = 0;
-  int j = 0;  // index of the current piece in dest[]
-  if (valid) {
-    p = seg_start[seg];
-    e = p + seg_len[seg];
-    j = seg_info[seg];
-  }
-  int coff[VPL];
   bool colok[VPL];
+  uint32_t cbytes[VPL];  // byte offset of this lane's vector in a row (clamped to 0 for lanes beyond ld)
 #pragma unroll
   for (int w = 0; w < VPL; ++w) {
-    coff[w] = (w * LPR + li) * VEC;
-    colok[w] = coff[w] < ld;
+    const int coff = (w * LPR + li) * VEC;
+    colok[w] = coff < ld;
+    cbytes[w] = colok[w] ? (uint32_t)coff * (uint32_t)sizeof(T) : 0u;
   }
-  T acc[VPL][VEC];
-#pragma unroll
-  for (int w = 0; w < VPL; ++w)
-#pragma unroll
-    for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
-
-  uint32_t cl = 0;
-  T vl = T(0);
-  {
-    const int64_t q = p + li;
-    if (q < e) {
-      cl = cols[q];
-      vl = vals[q];
+  const uint32_t rowbytes = (uint32_t)ld * (uint32_t)sizeof(T);
+  const uint32_t lds_rowbytes = (uint32_t)a.lds_ld * (uint32_t)sizeof(T);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.B), 0, WIDE ? 0u : a.tab_bytes, 0x00020000);
+  const int64_t n_waves = (a.n_seg + NG - 1) / NG;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave_stride = HOT ? ((int64_t)gridDim.x * blockDim.x) >> 6 : n_waves;
+  for (int64_t wave = wave0; wave < n_waves; wave += wave_stride) {
+    const int64_t seg = wave * NG + gi;
+    const uint32_t* cp = a.cols;
+    const T* vp = a.vals;
+    int rem = 0;  // nnz left in this group's segment
+    int j = 0;    // index of the current piece in dest[]
+    if (seg < a.n_seg) {
+      const int64_t s0 = a.seg_start[seg];
+      cp += s0;
+      vp += s0;
+      rem = a.seg_len[seg];
+      j = a.seg_info[seg];
     }
-  }
-  while (__any(p < e)) {
-    uint32_t cn = 0;
-    T vn = T(0);
-    {
-      const int64_t q = p + LPR + li;
-      if (q < e) {
-        cn = cols[q];
-        vn = vals[q];
-      }
+    T acc[VPL][VEC];
+#pragma unroll
+    for (int w = 0; w < VPL; ++w)
+#pragma unroll
+      for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
+    // chunk registers: lane li holds elements li*EPL + x of the chunk (col 0 / val 0 beyond the segment:
+    // such steps gather row 0, which is valid memory, and add 0)
+    uint32_t cl[EPL];
+    T vl[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+      const int q = li * EPL + x;
+      cl[x] = q < rem ? cp[q] : 0u;
+      vl[x] = q < rem ? vp[q] : T(0);
     }
+    // Retire the first chunk's loads before the loop: otherwise hipcc, merging "load still pending" from
+    // the loop entry with the back edge, puts a vmcnt(0) inside the loop right behind the prefetch of the
+    // next chunk and every chunk stalls for a full memory latency.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    while (__any(rem > 0)) {
+      uint32_t cn[EPL];
+      T vn[EPL];
 #pragma unroll
-    for (int u0 = 0; u0 < LPR; u0 += U) {
-      uint32_t c[U];
-      T v[U];
-      VT b[U][VPL];
-      int r[U];
-      bool act[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        c[u] = (uint32_t)shfl_i((int)cl, gbase + u0 + u);
-        v[u] = shfl_t(vl, gbase + u0 + u);
-        act[u] = (p + u0 + u) < e;
+      for (int x = 0; x < EPL; ++x) {
+        const int q = CH + li * EPL + x;
+        cn[x] = q < rem ? cp[q] : 0u;
+        vn[x] = q < rem ? vp[q] : T(0);
       }
-      int jj = j;
+      // destinations of the next CH pieces of this group: lane li holds dest[j + x*LPR + li]
+      int dl[EPL];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t col = (int64_t)(c[u] & ~kEndFlag);
-        const T* bp = B + col * ld;
+      for (int x = 0; x < EPL; ++x) {
+        const int64_t q = (int64_t)j + x * LPR + li;
+        dl[x] = (rem > 0 && q < a.n_dest) ? a.dest[q] : 0;
+      }
+      const int jbase = j;
+      static_for<CH / U>([&](auto ib) {
+        constexpr int u0 = decltype(ib)::value * U;
+        uint32_t c[U];
+        T v[U];
+        VT b[U][VPL];
+        // hand out (col, val) of step u0+u: lane (u0+u)/EPL of the group holds it in register (u0+u)%EPL
+        static_for<U>([&](auto iu) {
+          constexpr int u = decltype(iu)::value;
+          constexpr int t = u0 + u;
+          c[u] = (uint32_t)group_bcast_i<LPR, t / EPL>((int)cl[t % EPL], lane);
+          v[u] = group_bcast_t<LPR, t / EPL>(vl[t % EPL], lane);
+        });
 #pragma unroll
-        for (int w = 0; w < VPL; ++w) {
-          if (act[u] && colok[w]) {
-            b[u][w] = *reinterpret_cast<const VT*>(bp + coff[w]);
+        for (int u = 0; u < U; ++u) {
+          if (WIDE) {
+            const T* bp = a.B + (int64_t)(c[u] & ~kEndFlag) * ld;
+#pragma unroll
+            for (int w = 0; w < VPL; ++w) b[u][w] = *reinterpret_cast<const VT*>(reinterpret_cast<const char*>(bp) + cbytes[w]);
+          } else if (HOT) {
+            // hot rows: LDS read (always issued, cold lanes read row 0); cold rows: buffer load under the
+            // exec mask of the cold lanes only, into registers of its own (no load waits on another)
+            const uint32_t col = c[u] & ~kEndFlag;
+            const bool hot = col < (uint32_t)a.hot_rows;
+            const uint32_t lrow = __umul24(hot ? col : 0u, lds_rowbytes);
+#pragma unroll
+            for (int w = 0; w < VPL; ++w) {
+              const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + cbytes[w]);
+              U4 g;
+              if (!hot) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(col, rowbytes) + cbytes[w], 0, 0);
+              const U4 sel = hot ? l : g;
+              __builtin_memcpy(&b[u][w], &sel, sizeof(VT));
+            }
           } else {
 #pragma unroll
-            for (int x = 0; x < VEC; ++x) b[u][w].v[x] = T(0);
-          }
-        }
-        const bool endf = act[u] && (c[u] & kEndFlag);
-        r[u] = 0;
-        if (endf) r[u] = dest[jj];
-        jj += endf ? 1 : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int w = 0; w < VPL; ++w)
-#pragma unroll
-          for (int x = 0; x < VEC; ++x) acc[w][x] += v[u] * b[u][w].v[x];
-        if (act[u] && (c[u] & kEndFlag)) {
-          // destination of the finished piece: an output row, or a carry slot of a multi-piece row
-          T* op = r[u] >= 0 ? out + (int64_t)r[u] * ld : carry + (int64_t)(~r[u]) * ld;
-#pragma unroll
-          for (int w = 0; w < VPL; ++w) {
-            if (colok[w]) {
-              VT o;
-#pragma unroll
-              for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
-              *reinterpret_cast<VT*>(op + coff[w]) = o;
+            for (int w = 0; w < VPL; ++w) {
+              const uint32_t voff = __umul24(c[u], rowbytes) + cbytes[w];  // u24: the flag bit drops out
+#if MNMF_ABLATE == 1   // timing experiment only: no gather
+              asm volatile("" ::"v"(voff));
+              U4 g = {voff, 1u, 2u, 3u};
+#else
+              const U4 g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+#endif
+              __builtin_memcpy(&b[u][w], &g, sizeof(VT));
             }
-#pragma unroll
-            for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
           }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int w = 0; w < VPL; ++w)
+#pragma unroll
+            for (int x = 0; x < VEC; ++x) acc[w][x] += v[u] * b[u][w].v[x];
+#if MNMF_ABLATE == 3   // timing experiment only: no end-of-piece handling
+          const bool endf = false;
+#else
+          const bool endf = (c[u] & kEndFlag) != 0;
+#endif
+          if (__any(endf)) {  // wave-uniform: some group finished a piece at this step
+            const int idx = j - jbase;  // < CH
+            int d = shfl_i(dl[0], gbase + (idx % LPR));
+#pragma unroll
+            for (int x = 1; x < EPL; ++x) {
+              const int dx = shfl_i(dl[x], gbase + (idx % LPR));
+              d = (idx / LPR == x) ? dx : d;
+            }
+            if (endf) {
+              // destination of the finished piece: an output row, or a carry slot of a multi-piece row
+              T* op = d >= 0 ? a.out + (int64_t)d * ld : a.carry + (int64_t)(~d) * ld;
+#pragma unroll
+              for (int w = 0; w < VPL; ++w) {
+                if (colok[w]) {
+                  VT o;
+#pragma unroll
+                  for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
+                  *reinterpret_cast<VT*>(reinterpret_cast<char*>(op) + cbytes[w]) = o;
+                }
+#pragma unroll
+                for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
+              }
+              ++j;
+            }
+          }
+        }
+      });
+      rem -= CH;
+      cp += CH;
+      vp += CH;
+#pragma unroll
+      for (int x = 0; x < EPL; ++x) {
+        cl[x] = cn[x];
+        vl[x] = vn[x];
       }
-      j = jj;
     }
-    p = (p + LPR < e) ? p + LPR : e;
-    cl = cn;
-    vl = vn;
   }
 }
 

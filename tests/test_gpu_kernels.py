@@ -147,3 +147,47 @@ def test_diff_norms(engines, dtype):
         assert abs(eng.diff_norm(A, B) - np.linalg.norm(d, 2)) <= tol * np.linalg.norm(d, 2)
         assert abs(eng.diff_norm(A, B, kind="fro") - np.linalg.norm(d, "fro")) <= tol * np.linalg.norm(d, "fro")
     assert eng.diff_norm(A, A) == 0.0
+
+
+@pytest.fixture(scope="module")
+def hot_engines():
+    """Engines forced onto the LDS-staged persistent SpMM path (normally used only for large matrices),
+    with an LDS budget small enough that hot and cold rows both occur."""
+    import os
+    from manta_amd.engine import Engine
+
+    old = {k_: os.environ.get(k_) for k_ in ("MNMF_HOT_MIN_NNZ", "MNMF_HOT_LDS_BYTES")}
+    os.environ["MNMF_HOT_MIN_NNZ"] = "0"
+    os.environ["MNMF_HOT_LDS_BYTES"] = "20000"
+    try:
+        e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    yield e
+    for x in e.values():
+        x.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("k", [5, 10, 50, 100, 130])
+def test_spmm_lds_hot_rows(hot_engines, dtype, k):
+    eng = hot_engines[dtype]
+    X = make_x(3000, 900, seed=100 + k, dense_cols=6)
+    eng.set_matrix(X)
+    rng = np.random.RandomState(k)
+    B = rng.rand(900, k)
+    A = rng.rand(3000, k)
+    assert rel(host(eng.spmm(B)), X @ B) <= TOL[dtype]
+    assert rel(host(eng.spmm(A, transpose=True)), X.T @ A) <= TOL[dtype]
+
+
+def test_solver_on_lds_hot_path(hot_engines, golden):
+    g = golden("fixed_B_1000x1200_k10")
+    eng = hot_engines["fp64"]
+    eng.set_matrix(g["X"])
+    W, H, _ = eng.run_nmf(g["W0"], g["H0"], fixed_iters=20, zero_threshold=1e-5)
+    assert rel(host(W), g["nmf_W_20"]) <= 1e-10 and rel(host(H), g["nmf_H_20"]) <= 1e-10

@@ -1,0 +1,9 @@
+run() { echo "== $*"; env "$@" timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['value'], d['roofline']['phase_ms_per_iter'])"; }
+run MNMF_HOT_LDS_BYTES=0
+run MNMF_HOT_LDS_BYTES=0 MNMF_LIB=$PWD/manta_amd/libmnmf_ab1.so
+run MNMF_HOT_LDS_BYTES=0 MNMF_LIB=$PWD/manta_amd/libmnmf_ab2.so
+run MNMF_HOT_LDS_BYTES=0 MNMF_LIB=$PWD/manta_amd/libmnmf_ab3.so
