@@ -41,13 +41,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--m", type=int, default=0)
-    ap.add_argument("--V", type=int, default=0)
-    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--docs", dest="m", type=int, default=0)
+    ap.add_argument("--vocab", dest="V", type=int, default=0)
+    ap.add_argument("--topics", dest="k", type=int, default=0)
     ap.add_argument("--density", type=float, default=0.0)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo only rehearses the N>1 path with several ranks on one GPU (exchange staged through the host)")
     return ap.parse_args()
 
 
@@ -69,10 +71,24 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def all_reduce(t, op=None):
+        """all-reduce of a small device tensor on whichever backend is in use"""
+        op = op or dist.ReduceOp.SUM
+        if args.backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     def barrier():
         if world > 1:
@@ -90,7 +106,7 @@ def main():
         # values were computed from local df; redo idf with the global df so the matrix is one TF-IDF
         df = torch.bincount(col.long(), minlength=V).double()
         df_g = df.clone()
-        dist.all_reduce(df_g)
+        all_reduce(df_g)
         scale = torch.log2((1.0 + m) / df_g.clamp(min=1.0)) / torch.log2((1.0 + m_loc) / df.clamp(min=1.0)).clamp(min=1e-30)
         val = val * scale[col.long()]
     val = val.to(tdt)
@@ -98,16 +114,16 @@ def main():
     nnz = nnz_loc
     if world > 1:
         t = torch.tensor([nnz_loc], device=dev, dtype=torch.int64)
-        dist.all_reduce(t)
+        all_reduce(t)
         nnz = int(t.item())
     xmax = float(val.max())
     if world > 1:
         t = torch.tensor([xmax], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         xmax = float(t.item())
     t_gen = time.time() - t_gen
 
-    eng = Engine(device=local_rank, dtype=args.dtype)
+    eng = Engine(device=dev_index, dtype=args.dtype)
     t_prep = time.time()
     eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(m_loc, V))
     torch.cuda.synchronize()
@@ -140,7 +156,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
