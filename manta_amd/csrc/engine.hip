@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "dense.hpp"
 #include "eig.hpp"
+#include "gram_mfma.hpp"
 #include "sparse_prep.hpp"
 #include "spmm.hpp"
 
@@ -78,6 +79,7 @@ struct Tune {
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
+  int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
@@ -89,6 +91,7 @@ struct Tune {
     permute_vocab = (int)geti("MNMF_PERMUTE_VOCAB", permute_vocab);
     hot_lds_bytes = geti("MNMF_HOT_LDS_BYTES", hot_lds_bytes);
     hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
+    mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
   }
 };
 
@@ -532,12 +535,46 @@ class Engine : public ImplBase {
     }
   }
 
+  template <int NT, int TR>
+  int gram_mfma_launch(const float* A, const float* A2, const float* B, const float* B2, int64_t rows, int ld, bool diff,
+                       float* out) {
+    const int64_t elems = (int64_t)ld * ld;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(2 * n_cus, cdiv(rows, 256)));
+    const int64_t rpb = round_up(cdiv(rows, blocks), 16);
+    const int64_t nb = cdiv(rows, rpb);
+    E_HIP(slab.ensure((size_t)nb * elems * sizeof(float)));
+    dim3 grid((unsigned)nb, (unsigned)(NT / TR));
+    if (diff) gram_mfma_f32_kernel<NT, TR, true><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, slab.template as<float>());
+    else gram_mfma_f32_kernel<NT, TR, false><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, slab.template as<float>());
+    E_LAUNCH();
+    slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(slab.template as<float>(), nb, elems, out);
+    E_LAUNCH();
+    return 0;
+  }
+
   // out (ld x ld) = A^T B over rows;  diff: operands |A - A2|, |B - B2|
   int gram(const T* A, const T* A2, const T* B, const T* B2, int64_t rows, int ld, bool diff, T* out) {
     const int64_t elems = (int64_t)ld * ld;
     if (rows <= 0) {
       E_HIP(hipMemsetAsync(out, 0, elems * sizeof(T), st()));
       return 0;
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (tune.mfma_gram && ld <= 256) {  // matrix-core path (fp32); fp64 and ld > 256 use the VALU tiles below
+        const float* a = (const float*)A; const float* a2 = (const float*)A2;
+        const float* b = (const float*)B; const float* b2 = (const float*)B2;
+        float* o = (float*)out;
+        switch ((ld + 31) / 32) {
+          case 1: return gram_mfma_launch<1, 1>(a, a2, b, b2, rows, ld, diff, o);
+          case 2: return gram_mfma_launch<2, 2>(a, a2, b, b2, rows, ld, diff, o);
+          case 3: return gram_mfma_launch<3, 1>(a, a2, b, b2, rows, ld, diff, o);
+          case 4: return gram_mfma_launch<4, 1>(a, a2, b, b2, rows, ld, diff, o);
+          case 5: return gram_mfma_launch<5, 1>(a, a2, b, b2, rows, ld, diff, o);
+          case 6: return gram_mfma_launch<6, 1>(a, a2, b, b2, rows, ld, diff, o);
+          case 7: return gram_mfma_launch<7, 1>(a, a2, b, b2, rows, ld, diff, o);
+          default: return gram_mfma_launch<8, 1>(a, a2, b, b2, rows, ld, diff, o);
+        }
+      }
     }
     const int64_t rpc = std::max<int64_t>(256, round_up(cdiv(rows, 1024), 16));
     const int64_t chunks = cdiv(rows, rpc);
