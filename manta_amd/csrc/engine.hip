@@ -73,7 +73,7 @@ struct DevBuf {
 // Tunables (environment overrides are for experiments; defaults are what the benchmarks use).
 struct Tune {
   int64_t x_q = 512;                  // target nnz per segment, X stream
-  int64_t xt_q = 512;                 // target nnz per segment, X^T stream
+  int64_t xt_q = 128;                 // target nnz per segment, X^T stream (small: one XCD stays inside one document block)
   int64_t xt_block_bytes = 2 << 20;   // bytes of W rows per document block of X^T
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32

@@ -14,6 +14,16 @@
 #ifndef MNMF_ABLATE
 #define MNMF_ABLATE 0
 #endif
+// Non-temporal loads of the nnz stream were measured slower (C2: X^T.W 2.03 -> 2.16 ms): every 64-byte
+// group read is half a line and the second half no longer hits; kept only as an experiment switch.
+#ifndef MNMF_STREAM_NT
+#define MNMF_STREAM_NT 0
+#endif
+#if MNMF_STREAM_NT
+#define MNMF_NT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define MNMF_NT_LOAD(p) (*(p))
+#endif
 
 namespace mnmf {
 
@@ -112,8 +122,8 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
 #pragma unroll
     for (int x = 0; x < EPL; ++x) {
       const int q = li * EPL + x;
-      cl[x] = q < rem ? cp[q] : 0u;
-      vl[x] = q < rem ? vp[q] : T(0);
+      cl[x] = q < rem ? MNMF_NT_LOAD(cp + q) : 0u;
+      vl[x] = q < rem ? MNMF_NT_LOAD(vp + q) : T(0);
     }
     // Retire the first chunk's loads before the loop: otherwise hipcc, merging "load still pending" from
     // the loop entry with the back edge, puts a vmcnt(0) inside the loop right behind the prefetch of the
@@ -125,8 +135,8 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
 #pragma unroll
       for (int x = 0; x < EPL; ++x) {
         const int q = CH + li * EPL + x;
-        cn[x] = q < rem ? cp[q] : 0u;
-        vn[x] = q < rem ? vp[q] : T(0);
+        cn[x] = q < rem ? MNMF_NT_LOAD(cp + q) : 0u;
+        vn[x] = q < rem ? MNMF_NT_LOAD(vp + q) : T(0);
       }
       // destinations of the next CH pieces of this group: lane li holds dest[j + x*LPR + li]
       int dl[EPL];
