@@ -172,22 +172,30 @@ __global__ __launch_bounds__(256) void dense_rk_kernel(RkArgs<T> a) {
   const int col = c0 + tx * 4;
   if (col >= ld) return;  // ld % 4 == 0: a thread's 4 columns are all inside or all outside
   using V4 = Vec<T, 4>;
+  // loads of all four rows before the first store: out may alias nothing here, but the compiler cannot know
+  V4 u[4], n[4];
+  if (MODE != RK_PROD) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = row0 + ty * 4 + i;
+      const int64_t off = (row < a.rows ? row : a.rows - 1) * ld + col;
+      u[i] = *reinterpret_cast<const V4*>(a.upd + off);
+      n[i] = *reinterpret_cast<const V4*>(a.num + off);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t row = row0 + ty * 4 + i;
     if (row >= a.rows) continue;
     const int64_t off = row * ld + col;
     V4 o;
-    if (MODE == RK_PROD) {
 #pragma unroll
-      for (int jx = 0; jx < 4; ++jx) o.v[jx] = acc[i][jx];
-    } else {
-      const V4 u = *reinterpret_cast<const V4*>(a.upd + off);
-      const V4 n = *reinterpret_cast<const V4*>(a.num + off);
-#pragma unroll
-      for (int jx = 0; jx < 4; ++jx) {
-        const T q = n.v[jx] / (acc[i][jx] + a.eps);
-        o.v[jx] = u.v[jx] * (MODE == RK_MU_SQRT ? sqrt(q) : q);
+    for (int jx = 0; jx < 4; ++jx) {
+      if (MODE == RK_PROD) {
+        o.v[jx] = acc[i][jx];
+      } else {
+        const T q = n[i].v[jx] / (acc[i][jx] + a.eps);
+        o.v[jx] = u[i].v[jx] * (MODE == RK_MU_SQRT ? sqrt(q) : q);
       }
     }
     *reinterpret_cast<V4*>(a.out + off) = o;

@@ -80,6 +80,7 @@ struct Tune {
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
+  int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
@@ -92,6 +93,7 @@ struct Tune {
     hot_lds_bytes = geti("MNMF_HOT_LDS_BYTES", hot_lds_bytes);
     hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
+    mfma_rk = (int)geti("MNMF_MFMA_RK", mfma_rk);
   }
 };
 
@@ -544,8 +546,17 @@ class Engine : public ImplBase {
     const int64_t nb = cdiv(rows, rpb);
     E_HIP(slab.ensure((size_t)nb * elems * sizeof(float)));
     dim3 grid((unsigned)nb, (unsigned)(NT / TR));
-    if (diff) gram_mfma_f32_kernel<NT, TR, true><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, slab.template as<float>());
-    else gram_mfma_f32_kernel<NT, TR, false><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, slab.template as<float>());
+    float* sl = slab.template as<float>();
+    const bool sym = (A == B && A2 == B2);
+    if (sym) {
+      if (diff) gram_mfma_f32_kernel<NT, TR, true, true><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, sl);
+      else gram_mfma_f32_kernel<NT, TR, false, true><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, sl);
+    } else if constexpr (NT * TR <= 9) {  // a full TR x NT block of tiles has to fit the register file
+      if (diff) gram_mfma_f32_kernel<NT, TR, true, false><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, sl);
+      else gram_mfma_f32_kernel<NT, TR, false, false><<<grid, 512, 0, st()>>>(A, A2, B, B2, rows, ld, rpb, sl);
+    } else {
+      return fail(MNMF_EINVAL, "gram: tile shape reserved for symmetric products");
+    }
     E_LAUNCH();
     slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(slab.template as<float>(), nb, elems, out);
     E_LAUNCH();
@@ -567,8 +578,10 @@ class Engine : public ImplBase {
         switch ((ld + 31) / 32) {
           case 1: return gram_mfma_launch<1, 1>(a, a2, b, b2, rows, ld, diff, o);
           case 2: return gram_mfma_launch<2, 2>(a, a2, b, b2, rows, ld, diff, o);
-          case 3: return gram_mfma_launch<3, 1>(a, a2, b, b2, rows, ld, diff, o);
-          case 4: return gram_mfma_launch<4, 1>(a, a2, b, b2, rows, ld, diff, o);
+          case 3: return gram_mfma_launch<3, 3>(a, a2, b, b2, rows, ld, diff, o);
+          case 4:
+            if (a == b && a2 == b2) return gram_mfma_launch<4, 4>(a, a2, b, b2, rows, ld, diff, o);
+            return gram_mfma_launch<4, 2>(a, a2, b, b2, rows, ld, diff, o);
           case 5: return gram_mfma_launch<5, 1>(a, a2, b, b2, rows, ld, diff, o);
           case 6: return gram_mfma_launch<6, 1>(a, a2, b, b2, rows, ld, diff, o);
           case 7: return gram_mfma_launch<7, 1>(a, a2, b, b2, rows, ld, diff, o);
@@ -595,12 +608,38 @@ class Engine : public ImplBase {
          int64_t rows, int ld, double eps) {
     if (rows <= 0) return 0;
     RkArgs<T> a{A1, G1, A2, G2, upd, num, out, rows, ld, (T)eps};
+    if constexpr (sizeof(T) == 4) {
+      if (tune.mfma_rk && ld <= 256) return rk_mfma(mode, a);
+    }
     dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(ld, 64));
     if (mode == RK_PROD) dense_rk_kernel<T, RK_PROD><<<grid, 256, 0, st()>>>(a);
     else if (mode == RK_MU) dense_rk_kernel<T, RK_MU><<<grid, 256, 0, st()>>>(a);
     else dense_rk_kernel<T, RK_MU_SQRT><<<grid, 256, 0, st()>>>(a);
     E_LAUNCH();
     return 0;
+  }
+
+  template <int NT>
+  int rk_mfma_nt(int mode, const RkArgs<float>& a) {
+    constexpr int RT = NT <= 4 ? 2 : 1;
+    const unsigned grid = (unsigned)cdiv(a.rows, 128 * RT);
+    if (mode == RK_PROD) dense_rk_mfma_f32_kernel<NT, RT, RK_PROD><<<grid, 256, 0, st()>>>(a);
+    else if (mode == RK_MU) dense_rk_mfma_f32_kernel<NT, RT, RK_MU><<<grid, 256, 0, st()>>>(a);
+    else dense_rk_mfma_f32_kernel<NT, RT, RK_MU_SQRT><<<grid, 256, 0, st()>>>(a);
+    E_LAUNCH();
+    return 0;
+  }
+  int rk_mfma(int mode, const RkArgs<float>& a) {
+    switch ((a.ld + 31) / 32) {
+      case 1: return rk_mfma_nt<1>(mode, a);
+      case 2: return rk_mfma_nt<2>(mode, a);
+      case 3: return rk_mfma_nt<3>(mode, a);
+      case 4: return rk_mfma_nt<4>(mode, a);
+      case 5: return rk_mfma_nt<5>(mode, a);
+      case 6: return rk_mfma_nt<6>(mode, a);
+      case 7: return rk_mfma_nt<7>(mode, a);
+      default: return rk_mfma_nt<8>(mode, a);
+    }
   }
 
   int kxk(const T* A, const T* B, T* C, int ld, int ta, int tb) {
