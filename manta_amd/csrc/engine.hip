@@ -97,6 +97,8 @@ struct Tune {
   }
 };
 
+constexpr int kLongFix = 32;  // carry lists longer than this are summed by a whole block
+
 struct PhaseTimer {
   // HIP events on the solver's stream at phase boundaries; summed after the loop has drained.
   static constexpr int kMaxPhases = 8;
@@ -132,7 +134,7 @@ struct StreamMat {
   bool built = false, flags_set = false;
   int block_shift = -1;                      // X^T only: log2(documents per block)
   // segment description for the current seg_q
-  int64_t seg_q = -1, n_seg = 0, n_dest = 0, n_empty = 0, n_fix = 0, n_carry = 0;
+  int64_t seg_q = -1, n_seg = 0, n_dest = 0, n_empty = 0, n_fix = 0, n_fix_long = 0, n_carry = 0;
   int seg_group = -1;
   DevBuf seg_start, seg_len, seg_info, dest, empty_rows, fix_row, fix_first, fix_count, carry;
 };
@@ -433,6 +435,21 @@ class Engine : public ImplBase {
     M.n_empty = (int64_t)s.empty_rows.size();
     M.n_fix = (int64_t)s.fix_row.size();
     M.n_carry = s.n_carry;
+    {  // rows with long carry lists first: they get a block each (spmm_fixup_long_kernel), the rest a wave
+      std::vector<int32_t> order(s.fix_row.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)i;
+      auto mid = std::stable_partition(order.begin(), order.end(), [&](int32_t i) { return s.fix_count[i] > kLongFix; });
+      M.n_fix_long = (int64_t)(mid - order.begin());
+      std::vector<int32_t> r(order.size()), f(order.size()), c(order.size());
+      for (size_t i = 0; i < order.size(); ++i) {
+        r[i] = s.fix_row[order[i]];
+        f[i] = s.fix_first[order[i]];
+        c[i] = s.fix_count[order[i]];
+      }
+      s.fix_row.swap(r);
+      s.fix_first.swap(f);
+      s.fix_count.swap(c);
+    }
     MNMF_TRY(upload(M.seg_start, s.seg_start.data(), s.seg_start.size() * 8));
     MNMF_TRY(upload(M.seg_len, s.seg_len.data(), s.seg_len.size() * 4));
     MNMF_TRY(upload(M.seg_info, s.seg_info.data(), s.seg_info.size() * 4));
@@ -484,10 +501,16 @@ class Engine : public ImplBase {
       }
       E_LAUNCH();
     }
-    if (M.n_fix > 0) {
-      spmm_fixup_kernel<T, LPR, VPL><<<(unsigned)cdiv(M.n_fix, 4), 256, 0, st()>>>(
-          M.fix_row.template as<int32_t>(), M.fix_first.template as<int32_t>(), M.fix_count.template as<int32_t>(), M.n_fix, M.carry.template as<T>(),
-          ld, out);
+    const int32_t* fr = M.fix_row.template as<int32_t>();
+    const int32_t* ff = M.fix_first.template as<int32_t>();
+    const int32_t* fc = M.fix_count.template as<int32_t>();
+    if (M.n_fix_long > 0) {
+      spmm_fixup_long_kernel<T, LPR, VPL><<<(unsigned)M.n_fix_long, 256, 0, st()>>>(fr, ff, fc, M.carry.template as<T>(), ld, out);
+      E_LAUNCH();
+    }
+    if (M.n_fix > M.n_fix_long) {
+      const int64_t n = M.n_fix - M.n_fix_long, o = M.n_fix_long;
+      spmm_fixup_kernel<T, LPR, VPL><<<(unsigned)cdiv(n, 4), 256, 0, st()>>>(fr + o, ff + o, fc + o, n, M.carry.template as<T>(), ld, out);
       E_LAUNCH();
     }
     return 0;

@@ -296,6 +296,70 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t* __restri
   }
 }
 
+// One 256-thread block per row with a long carry list (hot words own thousands of segments): the 4*NG lane
+// groups stride the list, the groups of a wave are folded by shuffles and the four waves through LDS in wave
+// order -- a fixed summation tree, so the result does not depend on timing.
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void spmm_fixup_long_kernel(const int32_t* __restrict__ fix_row,
+                                                              const int32_t* __restrict__ fix_first,
+                                                              const int32_t* __restrict__ fix_count,
+                                                              const T* __restrict__ carry, int ld,
+                                                              T* __restrict__ out) {
+  constexpr int VEC = VecOf<T>::N;
+  using VT = typename VecOf<T>::type;
+  constexpr int NG = kWave / LPR;
+  __shared__ T part[4][LPR * VPL * VEC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const int64_t item = blockIdx.x;
+  const int64_t first = fix_first[item];
+  const int n = fix_count[item];
+  T acc[VPL][VEC];
+#pragma unroll
+  for (int w = 0; w < VPL; ++w)
+#pragma unroll
+    for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
+#pragma unroll 4
+  for (int s = wv * NG + gi; s < n; s += 4 * NG) {
+    const T* cp = carry + (first + s) * ld;
+#pragma unroll
+    for (int w = 0; w < VPL; ++w) {
+      const int co = (w * LPR + li) * VEC;
+      if (co < ld) {
+        const VT t = *reinterpret_cast<const VT*>(cp + co);
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) acc[w][x] += t.v[x];
+      }
+    }
+  }
+#pragma unroll
+  for (int mask = LPR; mask < kWave; mask <<= 1)
+#pragma unroll
+    for (int w = 0; w < VPL; ++w)
+#pragma unroll
+      for (int x = 0; x < VEC; ++x) acc[w][x] += shfl_xor_t(acc[w][x], mask);
+  if (gi == 0) {
+#pragma unroll
+    for (int w = 0; w < VPL; ++w)
+#pragma unroll
+      for (int x = 0; x < VEC; ++x) part[wv][(w * LPR + li) * VEC + x] = acc[w][x];
+  }
+  __syncthreads();
+  if (wv == 0 && gi == 0) {
+    T* op = out + (int64_t)fix_row[item] * ld;
+#pragma unroll
+    for (int w = 0; w < VPL; ++w) {
+      const int co = (w * LPR + li) * VEC;
+      if (co < ld) {
+        VT o;
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) o.v[x] = ((part[0][co + x] + part[1][co + x]) + part[2][co + x]) + part[3][co + x];
+        *reinterpret_cast<VT*>(op + co) = o;
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void zero_rows_kernel(const int32_t* __restrict__ rows, int64_t n, int ld, T* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
