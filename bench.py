@@ -33,6 +33,28 @@ CONFIGS = {
     "c4": ("nmtf", 2_000_000, 200_000, 0.0005, 20),
 }
 HBM_PEAK_GBS = 8000.0
+L1_GATHER_PEAK_GBS = 28000.0   # measured on MI355X with tools/l1_probe.hip (profiles/r01_l1_gather_probe.txt)
+
+
+def pmc_traffic(config, dtype, direction):
+    """HBM-side bytes per launch of the dominant SpMM from the committed rocprofv3 counter passes
+    (tools/prof_pmc.sh -> tools/pmc_summary.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
+    plus WRITE_SIZE).  Counters cannot be read from inside this process, so the figure is the one measured on the
+    same command and committed under profiles/; None when there is no summary for this config."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{config}_pmc_summary.json")))
+    if not files or dtype != "fp32":
+        return None, None
+    try:
+        rows = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None, None
+    for r in rows:
+        mm = re.search(r"spmm_stream_kernel<float, \d+, \d+, (\d)", r.get("kernel", ""))
+        if mm and int(mm.group(1)) == direction:
+            return int((r["fetch_MB_corrected"] + r["write_MB"]) * 1e6), os.path.relpath(files[-1], ROOT)
+    return None, None
 
 
 def parse():
@@ -181,10 +203,18 @@ def main():
     dom = max(alg_bytes, key=lambda n: phases.get(n, 0.0))
     dom_ms = phases[dom]
     achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    ld = (k + 3) // 4 * 4 if k <= 32 else (k + 15) // 16 * 16   # the engine's padded row width
+    traffic, traffic_src = pmc_traffic(args.config, args.dtype, 1 if dom == "spmm_xt" else 0) if world == 1 else (None, None)
+    # secondary bound: every nnz pulls one ld-wide factor row through the vector memory path;
+    # tools/l1_probe.hip measured 28 TB/s for that access (16 B per lane, 4 rows per wave load) with every row in L1
+    gather_bytes = nnz_loc * ld * sv
     roofline = {"bound": "hbm", "kernel": "spmm_stream_kernel (" + ("X^T.W" if dom == "spmm_xt" else "X.H^T") + ")",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(dom_ms, 4),
+                "gather_bound": {"bytes_per_launch": gather_bytes, "achieved_GBps": round(gather_bytes / (dom_ms * 1e-3) / 1e9, 1),
+                                 "l1_hit_peak_GBps": L1_GATHER_PEAK_GBS,
+                                 "frac": round(gather_bytes / (dom_ms * 1e-3) / 1e9 / L1_GATHER_PEAK_GBS, 4)},
                 "phase_ms_per_iter": {n: round(v, 4) for n, v in phases.items() if v > 0},
                 "iteration_bytes_model": st.bytes_model,
                 "iteration_frac_of_hbm": round(st.bytes_model * value / world / 1e9 / HBM_PEAK_GBS, 4)}

@@ -80,6 +80,7 @@ struct Tune {
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
+  int rk_rt = 0;                      // row tiles per wave in that kernel (0: pick)
   int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   Tune() {
@@ -94,6 +95,7 @@ struct Tune {
     hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
     mfma_rk = (int)geti("MNMF_MFMA_RK", mfma_rk);
+    rk_rt = (int)geti("MNMF_RK_RT", rk_rt);
   }
 };
 
@@ -642,9 +644,8 @@ class Engine : public ImplBase {
     return 0;
   }
 
-  template <int NT>
+  template <int NT, int RT>
   int rk_mfma_nt(int mode, const RkArgs<float>& a) {
-    constexpr int RT = NT <= 4 ? 2 : 1;
     const unsigned grid = (unsigned)cdiv(a.rows, 128 * RT);
     if (mode == RK_PROD) dense_rk_mfma_f32_kernel<NT, RT, RK_PROD><<<grid, 256, 0, st()>>>(a);
     else if (mode == RK_MU) dense_rk_mfma_f32_kernel<NT, RT, RK_MU><<<grid, 256, 0, st()>>>(a);
@@ -653,15 +654,17 @@ class Engine : public ImplBase {
     return 0;
   }
   int rk_mfma(int mode, const RkArgs<float>& a) {
-    switch ((a.ld + 31) / 32) {
-      case 1: return rk_mfma_nt<1>(mode, a);
-      case 2: return rk_mfma_nt<2>(mode, a);
-      case 3: return rk_mfma_nt<3>(mode, a);
-      case 4: return rk_mfma_nt<4>(mode, a);
-      case 5: return rk_mfma_nt<5>(mode, a);
-      case 6: return rk_mfma_nt<6>(mode, a);
-      case 7: return rk_mfma_nt<7>(mode, a);
-      default: return rk_mfma_nt<8>(mode, a);
+    const int nt = (a.ld + 31) / 32;
+    const bool two = tune.rk_rt > 0 ? tune.rk_rt == 2 : false;  // row tiles per wave
+    switch (nt) {
+      case 1: return two ? rk_mfma_nt<1, 2>(mode, a) : rk_mfma_nt<1, 1>(mode, a);
+      case 2: return two ? rk_mfma_nt<2, 2>(mode, a) : rk_mfma_nt<2, 1>(mode, a);
+      case 3: return two ? rk_mfma_nt<3, 2>(mode, a) : rk_mfma_nt<3, 1>(mode, a);
+      case 4: return two ? rk_mfma_nt<4, 2>(mode, a) : rk_mfma_nt<4, 1>(mode, a);
+      case 5: return rk_mfma_nt<5, 1>(mode, a);
+      case 6: return rk_mfma_nt<6, 1>(mode, a);
+      case 7: return rk_mfma_nt<7, 1>(mode, a);
+      default: return rk_mfma_nt<8, 1>(mode, a);
     }
   }
 

@@ -191,3 +191,48 @@ def test_solver_on_lds_hot_path(hot_engines, golden):
     eng.set_matrix(g["X"])
     W, H, _ = eng.run_nmf(g["W0"], g["H0"], fixed_iters=20, zero_threshold=1e-5)
     assert rel(host(W), g["nmf_W_20"]) <= 1e-10 and rel(host(H), g["nmf_H_20"]) <= 1e-10
+
+
+@pytest.fixture(scope="module")
+def small_segment_engines():
+    """Engines with 8-nnz segments: every long row is cut into many segments, so its carry list is long enough
+    (> 32 slots) for the block-per-row fix-up kernel, and short rows still take the wave-per-row one."""
+    import os
+    from manta_amd.engine import Engine
+
+    keys = ("MNMF_X_Q", "MNMF_XT_Q")
+    old = {k_: os.environ.get(k_) for k_ in keys}
+    for k_ in keys:
+        os.environ[k_] = "8"
+    try:
+        e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    yield e
+    for x in e.values():
+        x.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("k", [3, 10, 50, 100, 130])
+def test_spmm_long_carry_lists(small_segment_engines, dtype, k):
+    eng = small_segment_engines[dtype]
+    X = make_x(3000, 900, seed=200 + k, dense_cols=4)
+    assert (np.diff(X.tocsc().indptr) > 32 * 8 * 2).any()
+    eng.set_matrix(X)
+    rng = np.random.RandomState(k)
+    B = rng.rand(900, k)
+    A = rng.rand(3000, k)
+    r1 = host(eng.spmm(A, transpose=True))
+    assert rel(r1, X.T @ A) <= TOL[dtype]
+    assert np.array_equal(r1, host(eng.spmm(A, transpose=True)))      # fixed summation tree: bit-reproducible
+    assert rel(host(eng.spmm(B)), X @ B) <= TOL[dtype]
+    Xl = sp.random(30, 4000, density=0.4, format="csr", random_state=rng)  # long rows of X itself
+    Xl.sort_indices()
+    eng.set_matrix(Xl)
+    B = rng.rand(4000, k)
+    assert rel(host(eng.spmm(B)), Xl @ B) <= TOL[dtype]
