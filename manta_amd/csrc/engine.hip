@@ -80,7 +80,7 @@ struct Tune {
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
-  int rk_rt = 0;                      // row tiles per wave in that kernel (0: pick)
+  int fuse_grams = 1;                 // Grams of the new factor / of |new - old| inside the update kernel (k <= 64)
   int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   Tune() {
@@ -95,7 +95,7 @@ struct Tune {
     hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
     mfma_rk = (int)geti("MNMF_MFMA_RK", mfma_rk);
-    rk_rt = (int)geti("MNMF_RK_RT", rk_rt);
+    fuse_grams = (int)geti("MNMF_FUSE_GRAMS", fuse_grams);
   }
 };
 
@@ -634,7 +634,7 @@ class Engine : public ImplBase {
     if (rows <= 0) return 0;
     RkArgs<T> a{A1, G1, A2, G2, upd, num, out, rows, ld, (T)eps};
     if constexpr (sizeof(T) == 4) {
-      if (tune.mfma_rk && ld <= 256) return rk_mfma(mode, a);
+      if (tune.mfma_rk && ld <= 256 && (ld <= 32 || ld % 16 == 0)) return rk_mfma(mode, a);
     }
     dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(ld, 64));
     if (mode == RK_PROD) dense_rk_kernel<T, RK_PROD><<<grid, 256, 0, st()>>>(a);
@@ -644,27 +644,82 @@ class Engine : public ImplBase {
     return 0;
   }
 
-  template <int NT, int RT>
+  template <int NT>
   int rk_mfma_nt(int mode, const RkArgs<float>& a) {
-    const unsigned grid = (unsigned)cdiv(a.rows, 128 * RT);
-    if (mode == RK_PROD) dense_rk_mfma_f32_kernel<NT, RT, RK_PROD><<<grid, 256, 0, st()>>>(a);
-    else if (mode == RK_MU) dense_rk_mfma_f32_kernel<NT, RT, RK_MU><<<grid, 256, 0, st()>>>(a);
-    else dense_rk_mfma_f32_kernel<NT, RT, RK_MU_SQRT><<<grid, 256, 0, st()>>>(a);
+    const int64_t n_tiles = cdiv(a.rows, 32);
+    const unsigned grid = (unsigned)cdiv(n_tiles, 4);
+    if (mode == RK_PROD) dense_rk_mfma_f32_kernel<NT, RK_PROD, 0><<<grid, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    else if (mode == RK_MU) dense_rk_mfma_f32_kernel<NT, RK_MU, 0><<<grid, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    else dense_rk_mfma_f32_kernel<NT, RK_MU_SQRT, 0><<<grid, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
     E_LAUNCH();
     return 0;
   }
+
+  // update + the Grams of the new factor and of |new - old| in one pass (fp32, ld <= 64)
+  template <int NT, int MODE, int FUSE>
+  int rk_fused_launch(const RkArgs<float>& a, float* gram_new, float* gram_diff) {
+    const int64_t elems = (int64_t)a.ld * a.ld;
+    const int64_t n_tiles = cdiv(a.rows, 32);
+    const int64_t nb = std::max<int64_t>(1, std::min<int64_t>(cdiv(n_tiles, 4), 2 * (int64_t)n_cus));
+    E_HIP(slab.ensure((size_t)(2 * nb * elems) * sizeof(float)));
+    float* s_new = slab.template as<float>();
+    float* s_dif = s_new + nb * elems;
+    dense_rk_mfma_f32_kernel<NT, MODE, FUSE><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, s_new, s_dif);
+    E_LAUNCH();
+    if (FUSE & 1) {
+      slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(s_new, nb, elems, gram_new);
+      E_LAUNCH();
+    }
+    if (FUSE & 2) {
+      slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(s_dif, nb, elems, gram_diff);
+      E_LAUNCH();
+    }
+    return 0;
+  }
+  template <int NT>
+  int rk_fused_nt(int mode, const RkArgs<float>& a, float* gram_new, float* gram_diff) {
+    const int fuse = (gram_new ? 1 : 0) | (gram_diff ? 2 : 0);
+    if (mode == RK_MU) {
+      if (fuse == 3) return rk_fused_launch<NT, RK_MU, 3>(a, gram_new, gram_diff);
+      if (fuse == 1) return rk_fused_launch<NT, RK_MU, 1>(a, gram_new, gram_diff);
+      return rk_fused_launch<NT, RK_MU, 2>(a, gram_new, gram_diff);
+    }
+    if (fuse == 3) return rk_fused_launch<NT, RK_MU_SQRT, 3>(a, gram_new, gram_diff);
+    if (fuse == 1) return rk_fused_launch<NT, RK_MU_SQRT, 1>(a, gram_new, gram_diff);
+    return rk_fused_launch<NT, RK_MU_SQRT, 2>(a, gram_new, gram_diff);
+  }
+  bool can_fuse(int ld) const {
+    return sizeof(T) == 4 && tune.mfma_rk && tune.mfma_gram && tune.fuse_grams && (ld <= 32 || ld == 48 || ld == 64);
+  }
+
+  // rk() followed by gram(out) -> gram_new and gram(|out - upd|) -> gram_diff (either may be null); one pass
+  // over the rows where the fused kernel applies, separate passes otherwise.  The results are the same either way
+  // up to summation order.
+  int rk_grams(int mode, const T* A1, const T* G1, const T* A2, const T* G2, const T* upd, const T* num, T* out,
+               int64_t rows, int ld, double eps, T* gram_new, T* gram_diff) {
+    if (!gram_new && !gram_diff) return rk(mode, A1, G1, A2, G2, upd, num, out, rows, ld, eps);
+    if constexpr (sizeof(T) == 4) {
+      if (can_fuse(ld) && rows > 0 && mode != RK_PROD) {
+        RkArgs<float> a{A1, G1, A2, G2, upd, num, out, rows, ld, (float)eps};
+        return ld <= 32 ? rk_fused_nt<1>(mode, a, gram_new, gram_diff) : rk_fused_nt<2>(mode, a, gram_new, gram_diff);
+      }
+    }
+    MNMF_TRY(rk(mode, A1, G1, A2, G2, upd, num, out, rows, ld, eps));
+    if (gram_new) MNMF_TRY(gram(out, nullptr, out, nullptr, rows, ld, false, gram_new));
+    if (gram_diff) MNMF_TRY(gram(out, upd, out, upd, rows, ld, true, gram_diff));
+    return 0;
+  }
+
   int rk_mfma(int mode, const RkArgs<float>& a) {
-    const int nt = (a.ld + 31) / 32;
-    const bool two = tune.rk_rt > 0 ? tune.rk_rt == 2 : false;  // row tiles per wave
-    switch (nt) {
-      case 1: return two ? rk_mfma_nt<1, 2>(mode, a) : rk_mfma_nt<1, 1>(mode, a);
-      case 2: return two ? rk_mfma_nt<2, 2>(mode, a) : rk_mfma_nt<2, 1>(mode, a);
-      case 3: return two ? rk_mfma_nt<3, 2>(mode, a) : rk_mfma_nt<3, 1>(mode, a);
-      case 4: return two ? rk_mfma_nt<4, 2>(mode, a) : rk_mfma_nt<4, 1>(mode, a);
-      case 5: return rk_mfma_nt<5, 1>(mode, a);
-      case 6: return rk_mfma_nt<6, 1>(mode, a);
-      case 7: return rk_mfma_nt<7, 1>(mode, a);
-      default: return rk_mfma_nt<8, 1>(mode, a);
+    switch ((a.ld + 31) / 32) {
+      case 1: return rk_mfma_nt<1>(mode, a);
+      case 2: return rk_mfma_nt<2>(mode, a);
+      case 3: return rk_mfma_nt<3>(mode, a);
+      case 4: return rk_mfma_nt<4>(mode, a);
+      case 5: return rk_mfma_nt<5>(mode, a);
+      case 6: return rk_mfma_nt<6>(mode, a);
+      case 7: return rk_mfma_nt<7>(mode, a);
+      default: return rk_mfma_nt<8>(mode, a);
     }
   }
 
@@ -798,6 +853,7 @@ class Engine : public ImplBase {
     double w_norm = INFINITY, h_norm = INFINITY;
     int64_t i = 0;
     int converged = 0;
+    bool gw_valid = false;  // Gw holds this rank's w.T@w of the current w (left there by the previous w update)
     LoopClock clk;
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
@@ -808,24 +864,23 @@ class Engine : public ImplBase {
       T* Wn = Wb[1 - cw].template as<T>();
       T* Hc = Hb[ch].template as<T>();
       T* Hn = Hb[1 - ch].template as<T>();
-      MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gw));      // wT_w                nmf_basic.py:39
+      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+      if (!gw_valid) MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gw));  // wT_w       nmf_basic.py:39
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
       pt.mark(1);
       MNMF_TRY(allreduce(Nh, (int64_t)V * ld + (int64_t)ld * ld));
-      MNMF_TRY(rk(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps));  // h update       :41-42
+      // h update :41-42, with h_hT of the new h (:44) and, for the norms, D^T D of D = |h - h_old| (:53) in the same pass
+      MNMF_TRY(rk_grams(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps, Gh, do_check ? Gd + (size_t)ld * ld : nullptr));
       pt.mark(2);
-      MNMF_TRY(gram(Hn, nullptr, Hn, nullptr, V, ld, false, Gh));      // h_hT (new h)         :44
-      pt.mark(3);
       MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                            // in_mat @ h.T         :45
       pt.mark(4);
-      MNMF_TRY(rk(RK_MU, Wc, Gh, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps));  // w update :46-47
+      // w update :46-47, with the next iteration's wT_w (:39) and D^T D of D = |w - w_old| (:52)
+      MNMF_TRY(rk_grams(RK_MU, Wc, Gh, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw, do_check ? Gd : nullptr));
+      gw_valid = true;
       pt.mark(5);
-      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
       if (do_check) {
-        MNMF_TRY(gram(Wn, Wc, Wn, Wc, m, ld, true, Gd));                // D^T D, D = |w - w_old|   :52
         MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
-        MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + (size_t)ld * ld));  // :53
         MNMF_TRY(fetch_grams(Gd, 2, ld, g));
         w_norm = spectral_from_gram(g.data(), ld);
         h_norm = spectral_from_gram(g.data() + (size_t)ld * ld, ld);
@@ -899,6 +954,7 @@ class Engine : public ImplBase {
     int64_t i = 0;
     int converged = 0;
     const int64_t limit = fixed > 0 ? fixed : max_iter;
+    bool wtw_valid = false;  // wtw holds this rank's W.T@W of the current W (left there by the previous update)
     LoopClock clk;
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
@@ -907,7 +963,8 @@ class Engine : public ImplBase {
     while (i < limit) {                                                  // nmf_projective_basic.py:61
       T* Wc = Wb[cw].template as<T>();
       T* Wn = Wb[1 - cw].template as<T>();
-      MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, wtw));      // wtw = W.T @ W       :68
+      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+      if (!wtw_valid) MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, wtw));  // wtw = W.T @ W   :68
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, vtw));                                   // vtw = X.T @ W       :69
       pt.mark(1);
@@ -918,11 +975,11 @@ class Engine : public ImplBase {
       MNMF_TRY(allreduce(wt_pay, (int64_t)ld * ld));
       pt.mark(3);
       // payda = W @ wt_pay + pay @ wtw + eps ; w_new = W * sqrt(pay / payda)                  :76-79
-      MNMF_TRY(rk(RK_MU_SQRT, Wc, wt_pay, pay, wtw, Wc, pay, Wn, m, ld, eps));
+      // ... with the next iteration's wtw (:68) and D^T D of D = |w_new - W| (:83) in the same pass
+      MNMF_TRY(rk_grams(RK_MU_SQRT, Wc, wt_pay, pay, wtw, Wc, pay, Wn, m, ld, eps, wtw, do_check ? Gd : nullptr));
+      wtw_valid = true;
       pt.mark(5);
-      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
       if (do_check) {
-        MNMF_TRY(gram(Wn, Wc, Wn, Wc, m, ld, true, Gd));                 // :83
         MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
         MNMF_TRY(fetch_grams(Gd, 1, ld, g));
         w_norm = spectral_from_gram(g.data(), ld);
@@ -1024,6 +1081,7 @@ class Engine : public ImplBase {
     pt.mark(-1);
     std::vector<double> g, sh;
     const unsigned kb = (unsigned)cdiv((int64_t)gel, 256);
+    bool hht_valid = false;  // hhT holds h @ h.T of the current h (left there by the previous h update)
     while (true) {
       T* Wc = Wb[cw].template as<T>();
       T* Wn = Wb[1 - cw].template as<T>();
@@ -1038,14 +1096,15 @@ class Engine : public ImplBase {
       pt.mark(2);
       MNMF_TRY(spmm(X, M1, ld, Nw.template as<T>()));                             // in_mat @ (h.T @ s.T)
       pt.mark(4);
-      MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));      // h @ h.T
+      if (!hht_valid) MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));  // h @ h.T
       pt.mark(3);
       MNMF_TRY(kxk(Sc, hhT, T1, ld, 0, 0));                              // s (h hT)
       MNMF_TRY(kxk(T1, Sc, Dm, ld, 0, 1));                               // s (h hT) sT
-      MNMF_TRY(rk(RK_MU, Wc, Dm, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps));
+      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+      // w update with w1.T @ w1 (:157) and, for the norms, D^T D of D = |w1 - w| (:179) in the same pass
+      MNMF_TRY(rk_grams(RK_MU, Wc, Dm, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw1, do_check ? Gd : nullptr));
       pt.mark(5);
       // ---- S update                                                   nmtf.py:156-158
-      MNMF_TRY(gram(Wn, nullptr, Wn, nullptr, m, ld, false, Gw1));      // w1.T @ w1
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wn, ld, Pt));                                    // (w1.T @ in_mat)^T
       pt.mark(1);
@@ -1060,13 +1119,12 @@ class Engine : public ImplBase {
       MNMF_TRY(rk(RK_PROD, Pt, Sn, nullptr, nullptr, nullptr, nullptr, M1, V, ld, 0));  // (s1.T @ P)^T = Pt s1
       MNMF_TRY(kxk(Sn, Gw1, T3, ld, 1, 0));                              // s1T (w1T w1)
       MNMF_TRY(kxk(T3, Sn, Qm, ld, 0, 0));                               // s1T (w1T w1) s1   (symmetric)
-      MNMF_TRY(rk(RK_MU, Hc, Qm, nullptr, nullptr, Hc, M1, Hn, V, ld, eps));
+      // h update with the next iteration's h @ h.T (:152) and D^T D of D = |h1 - h| (:181) in the same pass
+      MNMF_TRY(rk_grams(RK_MU, Hc, Qm, nullptr, nullptr, Hc, M1, Hn, V, ld, eps, hhT, do_check ? Gd + gel : nullptr));
+      hht_valid = true;
       pt.mark(2);
-      const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
       if (do_check) {                                                     // Frobenius norms   nmtf.py:179-181
-        MNMF_TRY(gram(Wn, Wc, Wn, Wc, m, ld, true, Gd));
         MNMF_TRY(allreduce(Gd, (int64_t)gel));
-        MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + gel));
         MNMF_TRY(fetch_grams(Gd, 2, ld, g));
         w_norm = fro_from_gram(g.data(), ld);
         h_norm = fro_from_gram(g.data() + gel, ld);

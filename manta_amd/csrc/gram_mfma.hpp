@@ -161,113 +161,201 @@ __global__ __launch_bounds__(512) void gram_mfma_f32_kernel(const float* __restr
 // G (ld x ld, cache resident) is read as coalesced 128-byte rows.  The next chunk's operands are fetched while
 // the current chunk's MFMAs run.  Out-of-range k / rows / columns are clamped (A is zeroed there), never branched.
 // The epilogue works in the accumulator layout (lane = column, two 128-byte row segments per access).
-template <int NT, int RT, int MODE>
-__global__ __launch_bounds__(256) void dense_rk_mfma_f32_kernel(RkArgs<float> a) {
-  using V4 = Vec<float, 4>;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// FUSE (NT <= 2 only): the Grams that the solvers need right after an update are accumulated in the same pass,
+// from the registers of the epilogue: bit 0 = (new)^T (new)  (the next iteration's w.T@w / h@h.T,
+// nmf_basic.py:39,44), bit 1 = D^T D with D = |new - old| (the convergence norms, :52-53).  In the accumulator layout
+// lane (c, h) holds rows rho + 4h of column c, which is a legal 32x32x2 operand pair (rows rho and rho + 4), so the
+// epilogue's values feed the MFMA directly.  A wave then owns several row tiles (grid-stride) and keeps the Gram
+// tiles in registers; blocks reduce through LDS in wave order and write one partial per block to the slabs.
+// Shapes: ld % 16 == 0 for NT >= 2 (the engine pads k > 32 that way); NT == 1 takes any ld % 4 == 0 (TAIL selects).
+// Memory access is through raw buffer descriptors rebuilt per tile (scalar work): the descriptor's size is the tile's
+// valid bytes, so rows past the end read 0 and their stores are dropped by the hardware bounds check, and columns
+// past ld (and, for NT == 1, k past ld) get a poisoned offset instead of a branch or a select.  Per-lane state is a
+// handful of 32-bit offsets; everything tile-dependent is scalar.
+template <int NT, int MODE, int FUSE>
+__global__ __launch_bounds__(256, (NT <= 2 && FUSE == 0) ? 3 : (NT <= 4 ? 2 : 1))  // min waves per SIMD
+void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restrict__ slab_new,
+                              float* __restrict__ slab_diff) {
+  static_assert(FUSE == 0 || (NT <= 2 && MODE != RK_PROD), "fused Grams: k <= 64");
+  using U4 = __attribute__((ext_vector_type(4))) unsigned int;
+  constexpr bool TAIL = (NT == 1);
+  constexpr int NTRI = NT * (NT + 1) / 2;
+  constexpr unsigned kPoison = 0x40000000u;  // beyond any descriptor size used here
+  constexpr int kFlags = 0x00020000;
+  __shared__ float red[FUSE ? NTRI * 16 * 64 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: tile bases stay scalar
   const int cl = lane & 31, rh = lane >> 5;
   const int ld = a.ld;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wv) * (32 * RT);
-  if (row0 >= a.rows) return;
-  f32x16 acc[RT][NT];
+  const unsigned rowb = (unsigned)ld * 4u;
+  bool cok[NT];
+  unsigned goff[NT], eoff[NT];  // byte offsets: G operand (row 8*rh, column), epilogue (row 4*rh, column)
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int q = 0; q < NT; ++q) {
+    const int col = 32 * q + cl;
+    cok[q] = col < ld;
+    goff[q] = cok[q] ? (unsigned)(8 * rh) * rowb + 4u * col : kPoison;
+    eoff[q] = cok[q] ? (unsigned)(4 * rh) * rowb + 4u * col : kPoison;
+  }
+  const unsigned aoff = (unsigned)cl * rowb + 32u * rh;  // A operand: row cl, 8 floats at column 8*rh
+  f32x16 gnew[(FUSE & 1) ? NTRI : 1], gdif[(FUSE & 2) ? NTRI : 1];
+  if (FUSE) {
+#pragma unroll
+    for (int x = 0; x < NTRI; ++x)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (FUSE & 1) gnew[x][e] = 0.f;
+        if (FUSE & 2) gdif[x][e] = 0.f;
+      }
+  }
+
+#pragma unroll 1
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tile * 32;
+    const int64_t tbase = row0 * ld;
+    const int rleft = (int)((a.rows - row0 < 32) ? a.rows - row0 : 32);   // valid rows in this tile
+    const unsigned tbytes = (unsigned)rleft * rowb;
+    f32x16 acc[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][q][e] = 0.f;
-  int64_t arow[RT];
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+#pragma unroll 1
+    for (int pair = 0; pair < 2; ++pair) {
+      const float* A = pair == 0 ? a.A1 : a.A2;
+      const float* G = pair == 0 ? a.G1 : a.G2;
+      if (A == nullptr) break;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + tbase), 0, tbytes, kFlags);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, (unsigned)ld * rowb, kFlags);
+      U4 an[2];
+      unsigned gn[8][NT];
+      auto fetch = [&](int k0) {
 #pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    int64_t r = row0 + 32 * t + cl;
-    arow[t] = (r < a.rows ? r : a.rows - 1) * ld;
-  }
-  int gcol[NT];
-#pragma unroll
-  for (int q = 0; q < NT; ++q) gcol[q] = (32 * q + cl < ld) ? 32 * q + cl : ld - 1;
-
-  for (int pair = 0; pair < 2; ++pair) {
-    const float* A = pair == 0 ? a.A1 : a.A2;
-    const float* G = pair == 0 ? a.G1 : a.G2;
-    if (A == nullptr) break;
-    V4 an[RT][2];
-    float gn[8][NT];
-    auto fetch = [&](int k0) {
-      const int kc = k0 + 8 * rh;
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int c = kc + 4 * x;
-        const bool ok = c < ld;
-        const int cc = ok ? c : ld - 4;
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          V4 v = *reinterpret_cast<const V4*>(A + arow[t] + cc);
-          if (!ok) v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.f;
-          an[t][x] = v;
+        for (int x = 0; x < 2; ++x) {
+          if (TAIL) {
+            const int c = k0 + 8 * rh + 4 * x;
+            an[x] = __builtin_amdgcn_raw_buffer_load_b128(ra, c < ld ? aoff + 4u * (k0 + 4 * x) : kPoison, 0, 0);
+          } else {
+            an[x] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + 16u * x, 4 * k0, 0);
+          }
         }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            if (TAIL) gn[s][q] = __builtin_amdgcn_raw_buffer_load_b32(rg, goff[q] + (unsigned)(k0 + s) * rowb, 0, 0);
+            else gn[s][q] = __builtin_amdgcn_raw_buffer_load_b32(rg, goff[q], (k0 + s) * (int)rowb, 0);
+          }
+      };
+      fetch(0);
+#pragma unroll 1
+      for (int k0 = 0; k0 < ld; k0 += 16) {
+        U4 ac[2];
+        unsigned gc[8][NT];
+        ac[0] = an[0];
+        ac[1] = an[1];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) gc[s][q] = gn[s][q];
+        if (k0 + 16 < ld) fetch(k0 + 16);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(ac[s >> 2][s & 3]), __uint_as_float(gc[s][q]),
+                                                          acc[q], 0, 0, 0);
       }
+    }
+    // epilogue in groups of EG accumulator rows: a group's loads are all issued before its first store; with FUSE
+    // the group's new values and differences go straight into the Gram MFMAs.
+    constexpr int EG = NT <= 2 ? 8 : 4;
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.num + (MODE != RK_PROD ? tbase : 0)), 0, tbytes, kFlags);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.upd + (MODE != RK_PROD ? tbase : 0)), 0, tbytes, kFlags);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + tbase, 0, tbytes, kFlags);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int kr = kc + s < ld ? kc + s : ld - 1;
-        const float* gp = G + (int64_t)kr * ld;
-#pragma unroll
-        for (int q = 0; q < NT; ++q) gn[s][q] = gp[gcol[q]];
-      }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < ld; k0 += 16) {
-      V4 ac[RT][2];
-      float gc[8][NT];
-#pragma unroll
-      for (int t = 0; t < RT; ++t) { ac[t][0] = an[t][0]; ac[t][1] = an[t][1]; }
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int q = 0; q < NT; ++q) gc[s][q] = gn[s][q];
-      if (k0 + 16 < ld) fetch(k0 + 16);
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
+    for (int e0 = 0; e0 < 16; e0 += EG) {
+      float nv[NT][EG], uv[NT][EG];
+      if (MODE != RK_PROD) {
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
-          for (int t = 0; t < RT; ++t)
-            acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][s >> 2].v[s & 3], gc[s][q], acc[t][q], 0, 0, 0);
+          for (int x = 0; x < EG; ++x) {
+            const int e = e0 + x;
+            const unsigned off = eoff[q] + (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;
+            nv[q][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, off, 0, 0));
+            uv[q][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, off, 0, 0));
+          }
+      }
+      float on[NT][EG], od[NT][EG];
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int x = 0; x < EG; ++x) {
+          const int e = e0 + x;
+          const int r = 4 * rh + (e & 3) + 8 * (e >> 2);
+          const unsigned off = eoff[q] + (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;
+          float o = acc[q][e];
+          if (MODE != RK_PROD) {
+            const float qn = nv[q][x] / (o + a.eps);
+            o = uv[q][x] * (MODE == RK_MU_SQRT ? sqrtf(qn) : qn);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, off, 0, 0);   // dropped when out of the tile
+          if (FUSE) {
+            const bool ok = cok[q] && r < rleft;
+            on[q][x] = ok ? o : 0.f;
+            od[q][x] = ok ? fabsf(o - uv[q][x]) : 0.f;
+          }
+        }
+      if (FUSE) {
+#pragma unroll
+        for (int x = 0; x < EG; ++x) {
+          int y = 0;
+#pragma unroll
+          for (int qa = 0; qa < NT; ++qa)
+#pragma unroll
+            for (int qb = qa; qb < NT; ++qb, ++y) {
+              if (FUSE & 1) gnew[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(on[qa][x], on[qb][x], gnew[y], 0, 0, 0);
+              if (FUSE & 2) gdif[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(od[qa][x], od[qb][x], gdif[y], 0, 0, 0);
+            }
+        }
+      }
     }
   }
-  // epilogue: all of a tile's loads are issued before its first store (the compiler cannot prove that out does not
-  // alias num/upd, and would otherwise wait for memory once per element)
-  const float* __restrict__ num = a.num;
-  const float* __restrict__ upd = a.upd;
-  float* __restrict__ out = a.out;
+  if (FUSE) {
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+    for (int which = 0; which < 2; ++which) {
+      if (!(FUSE & (1 << which))) continue;
+      __syncthreads();  // red is reused
+      for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      const int col = 32 * q + cl;
-      const bool cok = col < ld;
-      const int64_t rbase = row0 + 32 * t + 4 * rh;
-      float nv[16], uv[16];
-      if (MODE != RK_PROD) {
+          for (int x = 0; x < NTRI; ++x)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
-          const bool ok = cok && row < a.rows;
-          const int64_t off = ok ? row * ld + col : 0;
-          nv[e] = num[off];
-          uv[e] = upd[off];
+            for (int e = 0; e < 16; ++e) {
+              const int idx = (x * 16 + e) * 64 + lane;
+              const float v = which == 0 ? gnew[x][e] : gdif[x][e];
+              red[idx] = (w == 0) ? v : red[idx] + v;
+            }
         }
+        __syncthreads();
       }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
-        float o = acc[t][q][e];
-        if (MODE != RK_PROD) {
-          const float qn = nv[e] / (o + a.eps);
-          o = uv[e] * (MODE == RK_MU_SQRT ? sqrtf(qn) : qn);
+      float* dst = (which == 0 ? slab_new : slab_diff) + (int64_t)blockIdx.x * (int64_t)ld * ld;
+      for (int i = threadIdx.x; i < NTRI * 16 * 64; i += 256) {
+        const int l = i & 63, e = (i >> 6) & 15, x = i >> 10;
+        int qa = 0, qb = x;  // x -> (qa, qb), qa <= qb, row-major over the upper triangle
+        while (qb >= NT - qa) { qb -= NT - qa; ++qa; }
+        qb += qa;
+        const int gi = 32 * qa + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+        const int gj = 32 * qb + (l & 31);
+        if (gi < ld && gj < ld) {
+          const float v = red[i];
+          dst[(int64_t)gi * ld + gj] = v;
+          if (qb > qa) dst[(int64_t)gj * ld + gi] = v;
         }
-        if (cok && row < a.rows) out[row * ld + col] = o;
       }
     }
+  }
 }
 
 }  // namespace mnmf
