@@ -46,14 +46,15 @@ __device__ inline double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, k
 template <int LPR, int L>
 __device__ inline int group_bcast_i(int x, int lane) {
   static_assert(L >= 0 && L < LPR, "lane index out of the group");
+  // mov_dpp (no "old" operand): every lane is written, so there is no destination to initialise first
   if constexpr (LPR == 4) {
-    return __builtin_amdgcn_update_dpp(0, x, L | (L << 2) | (L << 4) | (L << 6), 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(x, L | (L << 2) | (L << 4) | (L << 6), 0xf, 0xf, true);
   } else if constexpr (LPR == 8) {
-    const int a = __builtin_amdgcn_update_dpp(0, x, 0x150 + L, 0xf, 0xf, false);
-    const int b = __builtin_amdgcn_update_dpp(0, x, 0x150 + 8 + L, 0xf, 0xf, false);
+    const int a = __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, true);
+    const int b = __builtin_amdgcn_mov_dpp(x, 0x150 + 8 + L, 0xf, 0xf, true);
     return (lane & 8) ? b : a;
   } else if constexpr (LPR == 16) {
-    return __builtin_amdgcn_update_dpp(0, x, 0x150 + L, 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, true);
   } else if constexpr (LPR == 32) {
     const int a = __builtin_amdgcn_readlane(x, L);
     const int b = __builtin_amdgcn_readlane(x, 32 + L);

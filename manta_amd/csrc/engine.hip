@@ -79,6 +79,12 @@ struct Tune {
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
+  int xt_hot_words = 512;             // X^T: this many of the most frequent words go through LDS tiles of W
+  int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
+  int tile_min_rows = 448;            // tile stream only if a tile holds at least this many documents ...
+  int tile_min_tiles_per_cu = 4;      // ... and there are this many tiles per CU
+  int tile_wgs_per_cu = 1;            // workgroups per CU in the tile kernel (1, 2 or 4)
+  int64_t xth_q = 96;                 // X^T tile stream: > 0 target nnz per segment; <= 0: equal split, -xth_q segments per lane group
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
   int fuse_grams = 1;                 // Grams of the new factor / of |new - old| inside the update kernel (k <= 64)
   int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
@@ -93,6 +99,13 @@ struct Tune {
     permute_vocab = (int)geti("MNMF_PERMUTE_VOCAB", permute_vocab);
     hot_lds_bytes = geti("MNMF_HOT_LDS_BYTES", hot_lds_bytes);
     hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
+    xt_hot_words = (int)geti("MNMF_XT_HOT_WORDS", xt_hot_words);
+    tile_lds_bytes = geti("MNMF_TILE_LDS_BYTES", tile_lds_bytes);
+    xth_q = geti("MNMF_XTH_Q", xth_q);
+    tile_min_rows = (int)geti("MNMF_TILE_MIN_ROWS", tile_min_rows);
+    tile_min_tiles_per_cu = (int)geti("MNMF_TILE_MIN_TILES_PER_CU", tile_min_tiles_per_cu);
+    tile_wgs_per_cu = (int)geti("MNMF_TILE_WGS", tile_wgs_per_cu);
+    if (tile_wgs_per_cu != 2 && tile_wgs_per_cu != 4) tile_wgs_per_cu = 1;
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
     mfma_rk = (int)geti("MNMF_MFMA_RK", mfma_rk);
     fuse_grams = (int)geti("MNMF_FUSE_GRAMS", fuse_grams);
@@ -135,6 +148,10 @@ struct StreamMat {
   HostPieces pieces;                         // processing-order pieces (host)
   bool built = false, flags_set = false;
   int block_shift = -1;                      // X^T only: log2(documents per block)
+  int tile_rows = 0;                         // X^T tile stream only: documents per LDS tile
+  int64_t n_tiles = 0;
+  int n_hot = 0;                             // words in the tile stream (renumbered ids < n_hot)
+  DevBuf tile_first;                         // [n_tiles + 1] first segment of each tile
   // segment description for the current seg_q
   int64_t seg_q = -1, n_seg = 0, n_dest = 0, n_empty = 0, n_fix = 0, n_fix_long = 0, n_carry = 0;
   int seg_group = -1;
@@ -162,7 +179,7 @@ class Engine : public ImplBase {
   Tune tune;
   int64_t m = 0, V = 0, nnz = 0;
   bool have_matrix = false;
-  StreamMat<T> X, Xt;
+  StreamMat<T> X, Xt, Xth;   // X; X^T blocked stream; X^T tile stream of the most frequent words
   std::vector<int64_t> h_rowptr;
   DevBuf d_rowptr;
   // vocabulary renumbering by descending document frequency (identical on every rank)
@@ -232,6 +249,7 @@ class Engine : public ImplBase {
       if (h_rowptr[r + 1] < h_rowptr[r]) return fail(MNMF_EINVAL, "set_matrix: rowptr not monotone");
     X = StreamMat<T>();
     Xt = StreamMat<T>();
+    Xth = StreamMat<T>();
     prepared = false;
     X.rows = m;
     X.tab_rows = V;
@@ -239,6 +257,9 @@ class Engine : public ImplBase {
     Xt.rows = V;
     Xt.tab_rows = m;
     Xt.nnz = nnz;
+    Xth.rows = V;
+    Xth.tab_rows = m;
+    Xth.nnz = 0;
     const size_t n = (size_t)std::max<int64_t>(nnz, 1);
     E_HIP(X.cols.ensure(n * 4));
     E_HIP(X.vals.ensure(n * sizeof(T)));
@@ -317,6 +338,8 @@ class Engine : public ImplBase {
     E_HIP(hipStreamSynchronize(st()));
     Xt.built = false;
     Xt.seg_q = -1;
+    Xth.built = false;
+    Xth.seg_q = -1;
     return 0;
   }
 
@@ -334,26 +357,32 @@ class Engine : public ImplBase {
     prepared = false;
     Xt.built = false;
     Xt.seg_q = -1;
+    Xth.built = false;
+    Xth.seg_q = -1;
     return 0;
   }
 
-  // Build X^T in processing order for document blocks of 2^bs rows (see sparse_prep.hpp).
-  int ensure_xt(int bs) {
-    if (Xt.built && (Xt.block_shift == bs || nnz == 0)) return 0;
-    while ((cdiv(m, (int64_t)1 << bs) + 1) * V >= ((int64_t)1 << 32)) ++bs;
-    if (Xt.built && Xt.block_shift == bs) return 0;
+  // Build X^T in processing order (see sparse_prep.hpp): the n_hot most frequent words as a tile stream (tiles of
+  // tile_rows documents, Xth), the rest blocked by document blocks of 2^bs rows (Xt).  n_hot == 0: everything in Xt.
+  int ensure_xt(int bs, int n_hot, int tile_rows) {
+    if (nnz == 0) return 0;
+    if (n_hot <= 0 || tile_rows <= 0) n_hot = 0, tile_rows = 1;
+    const uint32_t n_tiles = n_hot > 0 ? (uint32_t)cdiv(m, tile_rows) : 0;
+    if ((uint64_t)n_tiles * (uint64_t)n_hot >= ((uint64_t)1 << 31)) n_hot = 0;
+    const uint32_t hot_span = n_hot > 0 ? n_tiles * (uint32_t)n_hot : 0u;
+    while ((uint64_t)hot_span + (uint64_t)(cdiv(m, (int64_t)1 << bs) + 1) * (uint64_t)V >= ((uint64_t)1 << 32)) ++bs;
+    if (Xt.built && Xt.block_shift == bs && Xth.n_hot == n_hot && (n_hot == 0 || Xth.tile_rows == tile_rows)) return 0;
     const uint32_t n_blocks = (uint32_t)cdiv(m, (int64_t)1 << bs);
     const size_t n = (size_t)nnz;
     const int TB = 256;
     DevBuf rowid, iota, key, keys_out, perm, tmp, df, flag, pos, cnt, pkey;
-    E_HIP(Xt.cols.ensure(n * 4));
-    E_HIP(Xt.vals.ensure(n * sizeof(T)));
     E_HIP(rowid.ensure(n * 4));
     E_HIP(iota.ensure(n * 4));
     E_HIP(key.ensure(n * 4));
     E_HIP(keys_out.ensure(n * 4));
     E_HIP(perm.ensure(n * 4));
     E_HIP(df.ensure((size_t)V * 4));
+    E_HIP(cnt.ensure(8));
     E_HIP(hipMemsetAsync(df.p, 0, (size_t)V * 4, st()));
     MNMF_TRY(clear_x_flags());  // the histogram / keys need plain column ids
     expand_rowids_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(d_rowptr.template as<int64_t>(), m, nnz,
@@ -361,13 +390,31 @@ class Engine : public ImplBase {
     E_LAUNCH();
     col_histogram_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, df.template as<int32_t>());
     E_LAUNCH();
+    int64_t n_hot_nnz = 0;
+    if (n_hot > 0) {  // nnz of the tile stream = sum of the first n_hot document frequencies
+      size_t bytes = 0;
+      E_HIP(rocprim::reduce(nullptr, bytes, df.template as<int32_t>(), cnt.template as<int32_t>(), 0, (size_t)n_hot,
+                            rocprim::plus<int32_t>(), st()));
+      E_HIP(tmp.ensure(bytes));
+      E_HIP(rocprim::reduce(tmp.p, bytes, df.template as<int32_t>(), cnt.template as<int32_t>(), 0, (size_t)n_hot,
+                            rocprim::plus<int32_t>(), st()));
+      int32_t h = 0;
+      E_HIP(hipMemcpyAsync(&h, cnt.p, 4, hipMemcpyDeviceToHost, st()));
+      E_HIP(hipStreamSynchronize(st()));
+      n_hot_nnz = h;
+    }
+    E_HIP(Xt.cols.ensure(std::max<size_t>(n - (size_t)n_hot_nnz, 1) * 4));
+    E_HIP(Xt.vals.ensure(std::max<size_t>(n - (size_t)n_hot_nnz, 1) * sizeof(T)));
+    E_HIP(Xth.cols.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * 4));
+    E_HIP(Xth.vals.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * sizeof(T)));
     transpose_key_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), rowid.template as<uint32_t>(),
                                                                    df.template as<int32_t>(), nnz, V, bs, n_blocks,
-                                                                   (int32_t)kSubPiece, key.template as<uint32_t>());
+                                                                   (int32_t)kSubPiece, (uint32_t)n_hot, (uint32_t)tile_rows,
+                                                                   hot_span, key.template as<uint32_t>());
     E_LAUNCH();
-    {  // stable sort by (block, vocabulary id): documents stay ascending inside a piece
+    {  // stable sort by key: documents stay ascending inside a piece
       int bits = 1;
-      while (((int64_t)1 << bits) < ((int64_t)n_blocks + 1) * V) ++bits;
+      while (((int64_t)1 << bits) < (int64_t)hot_span + ((int64_t)n_blocks + 1) * V) ++bits;
       size_t bytes = 0;
       E_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.template as<uint32_t>(), keys_out.template as<uint32_t>(),
                                       iota.template as<uint32_t>(), perm.template as<uint32_t>(), n, 0u, (unsigned)bits, st()));
@@ -376,12 +423,11 @@ class Engine : public ImplBase {
                                       iota.template as<uint32_t>(), perm.template as<uint32_t>(), n, 0u, (unsigned)bits, st()));
     }
     gather_transposed_kernel<T><<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(
-        perm.template as<uint32_t>(), rowid.template as<uint32_t>(), X.vals.template as<T>(), nnz,
-        Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>());
+        perm.template as<uint32_t>(), rowid.template as<uint32_t>(), X.vals.template as<T>(), nnz, n_hot_nnz, (uint32_t)tile_rows,
+        Xth.cols.template as<uint32_t>(), Xth.vals.template as<T>(), Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>());
     E_LAUNCH();
     // piece starts = positions where the key changes
     E_HIP(flag.ensure(n));
-    E_HIP(cnt.ensure(8));
     piece_flag_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), nnz, flag.template as<uint8_t>());
     E_LAUNCH();
     uint32_t* d_pos = iota.template as<uint32_t>();  // iota is dead after the sort: reuse as the position list
@@ -404,20 +450,37 @@ class Engine : public ImplBase {
     E_HIP(hipMemcpyAsync(h_pos.data(), d_pos, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st()));
     E_HIP(hipMemcpyAsync(h_key.data(), pkey.p, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st()));
     E_HIP(hipStreamSynchronize(st()));
-    Xt.pieces.start.resize((size_t)n_pieces + 1);
-    Xt.pieces.row.resize(n_pieces);
-    Xt.pieces.block.resize(n_pieces);
+    HostPieces& hp = Xth.pieces;
+    HostPieces& cp = Xt.pieces;
+    hp = HostPieces();
+    cp = HostPieces();
     for (uint32_t i = 0; i < n_pieces; ++i) {
-      Xt.pieces.start[i] = h_pos[i];
-      Xt.pieces.row[i] = (int32_t)(h_key[i] % (uint64_t)V);
-      const uint32_t b = (uint32_t)(h_key[i] / (uint64_t)V);
-      Xt.pieces.block[i] = b >= n_blocks ? -1 : (int32_t)b;
+      if (h_key[i] < hot_span) {
+        hp.start.push_back(h_pos[i]);
+        hp.row.push_back((int32_t)(h_key[i] % (uint32_t)n_hot));
+        hp.block.push_back((int32_t)(h_key[i] / (uint32_t)n_hot));
+      } else {
+        const uint64_t kk = (uint64_t)h_key[i] - hot_span;
+        cp.start.push_back((int64_t)h_pos[i] - n_hot_nnz);
+        cp.row.push_back((int32_t)(kk % (uint64_t)V));
+        const uint32_t b = (uint32_t)(kk / (uint64_t)V);
+        cp.block.push_back(b >= n_blocks ? -1 : (int32_t)b);
+      }
     }
-    Xt.pieces.start[n_pieces] = nnz;
+    hp.start.push_back(n_hot_nnz);
+    cp.start.push_back(nnz - n_hot_nnz);
+    Xt.nnz = nnz - n_hot_nnz;
     Xt.block_shift = bs;
     Xt.built = true;
     Xt.flags_set = false;
     Xt.seg_q = -1;
+    Xth.nnz = n_hot_nnz;
+    Xth.n_hot = n_hot;
+    Xth.tile_rows = n_hot > 0 ? tile_rows : 0;
+    Xth.n_tiles = n_tiles;
+    Xth.built = true;
+    Xth.flags_set = false;
+    Xth.seg_q = -1;
     return 0;
   }
 
@@ -430,7 +493,11 @@ class Engine : public ImplBase {
   int ensure_segments(StreamMat<T>& M, int64_t q, int xcd_group) {
     if (M.seg_q == q && M.seg_group == xcd_group && M.flags_set) return 0;
     HostSegments s;
-    build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group);
+    std::vector<int32_t> tile_first;
+    const bool tiled = M.tile_rows > 0;
+    if (tiled && q <= 0) build_tile_segments_host(M.pieces, M.rows, M.n_tiles, (int)(-q), kSubPiece, s, tile_first);  // -q = groups
+    else build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group, tiled ? &tile_first : nullptr, M.n_tiles);
+    if (tiled) MNMF_TRY(upload(M.tile_first, tile_first.data(), tile_first.size() * 4));
     M.seg_group = xcd_group;
     M.n_seg = s.n_seg();
     M.n_dest = (int64_t)s.dest.size();
@@ -484,9 +551,20 @@ class Engine : public ImplBase {
                       (size_t)ld * sizeof(T) >= ((size_t)1 << 24);
     SpmmArgs<T> a{M.seg_start.template as<int64_t>(), M.seg_len.template as<int32_t>(), M.seg_info.template as<int32_t>(), M.n_seg,
                   M.cols.template as<uint32_t>(), M.vals.template as<T>(), M.dest.template as<int32_t>(), M.n_dest,
-                  B, ld, out, M.carry.template as<T>(), hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes};
-    if (waves > 0 && hot > 0 && !wide) {
-      auto kern = spmm_stream_kernel<T, LPR, VPL, 0, true, false>;
+                  B, ld, out, M.carry.template as<T>(), hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes,
+                  M.tile_first.template as<int32_t>(), (int)M.n_tiles, M.tile_rows, M.tab_rows};
+    if (&M == &Xth) {
+      if (waves > 0) {  // tile stream: every gather is an LDS read (indices are local to the tile)
+        auto kern = spmm_stream_kernel<T, LPR, VPL, 1, SPMM_TILE, false>;
+        const size_t lds_bytes = (size_t)M.tile_rows * lds_ld * sizeof(T);
+        E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        a.hot_rows = 0;
+        const int wgs = std::max(1, tune.tile_wgs_per_cu);  // workgroups per CU: one stages while another computes
+        kern<<<(unsigned)std::min<int64_t>((int64_t)n_cus * wgs, M.n_tiles), 1024 / wgs, lds_bytes, st()>>>(a);
+        E_LAUNCH();
+      }
+    } else if (waves > 0 && hot > 0 && !wide) {
+      auto kern = spmm_stream_kernel<T, LPR, VPL, 0, SPMM_HOT, false>;
       const size_t lds_bytes = (size_t)hot * lds_ld * sizeof(T);
       E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       kern<<<(unsigned)n_cus, 1024, lds_bytes, st()>>>(a);
@@ -495,11 +573,11 @@ class Engine : public ImplBase {
       a.hot_rows = 0;
       const unsigned grid = (unsigned)cdiv(waves, 4);
       if (&M == &Xt) {
-        if (wide) spmm_stream_kernel<T, LPR, VPL, 1, false, true><<<grid, 256, 0, st()>>>(a);
-        else spmm_stream_kernel<T, LPR, VPL, 1, false, false><<<grid, 256, 0, st()>>>(a);
+        if (wide) spmm_stream_kernel<T, LPR, VPL, 1, SPMM_PLAIN, true><<<grid, 256, 0, st()>>>(a);
+        else spmm_stream_kernel<T, LPR, VPL, 1, SPMM_PLAIN, false><<<grid, 256, 0, st()>>>(a);
       } else {
-        if (wide) spmm_stream_kernel<T, LPR, VPL, 0, false, true><<<grid, 256, 0, st()>>>(a);
-        else spmm_stream_kernel<T, LPR, VPL, 0, false, false><<<grid, 256, 0, st()>>>(a);
+        if (wide) spmm_stream_kernel<T, LPR, VPL, 0, SPMM_PLAIN, true><<<grid, 256, 0, st()>>>(a);
+        else spmm_stream_kernel<T, LPR, VPL, 0, SPMM_PLAIN, false><<<grid, 256, 0, st()>>>(a);
       }
       E_LAUNCH();
     }
@@ -526,15 +604,36 @@ class Engine : public ImplBase {
     const int vpl = nvec > 64 ? 2 : 1;
     const int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
     const int ng = kWave / lpr;
+    const int lds_ld = ld + VEC;
     MNMF_TRY(ensure_prepared());
     if (&M == &Xt) {
       // document block = rows of W that fit about half of one XCD's 4 MiB L2
       int bs = 8;
       while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= tune.xt_block_bytes) ++bs;
-      MNMF_TRY(ensure_xt(bs));
+      // tile stream for the most frequent words: documents per tile = what one workgroup's LDS holds
+      int n_hot = 0, tile_rows = 0;
+      if (vmap() && tune.xt_hot_words > 0 && nnz >= tune.hot_min_nnz) {
+        tile_rows = (int)std::min<int64_t>(tune.tile_lds_bytes / tune.tile_wgs_per_cu / ((int64_t)lds_ld * (int64_t)sizeof(T)), 1 << 15);
+        n_hot = (int)std::min<int64_t>(tune.xt_hot_words, V / 2);
+        // worth it only with long pieces (>= ~450 documents per tile: fewer carries than gathers saved; measured
+        // C2 +6 %, C4 +8 %, but C3 with 344-document tiles -4 %) and enough tiles to balance the CUs
+        const int64_t min_rows = tune.tile_min_rows, min_tiles = (int64_t)tune.tile_min_tiles_per_cu * n_cus;
+        if (tile_rows < min_rows || n_hot < 8 || cdiv(m, tile_rows) < std::max<int64_t>(min_tiles, 4)) n_hot = 0;
+      }
+      MNMF_TRY(ensure_xt(bs, n_hot, tile_rows));
     }
-    int64_t q = (&M == &Xt) ? tune.xt_q : tune.x_q;
-    while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
+    MNMF_TRY(spmm_stream(M, B, ld, out, lpr, vpl, ng, lds_ld));
+    if (&M == &Xt && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld));
+    return 0;
+  }
+
+  int spmm_stream(StreamMat<T>& M, const T* B, int ld, T* out, int lpr, int vpl, int ng, int lds_ld) {
+    int64_t q = (&M == &Xt) ? tune.xt_q : (&M == &Xth) ? tune.xth_q : tune.x_q;
+    if (&M == &Xth) {
+      if (q <= 0) q = -(int64_t)(16 / tune.tile_wgs_per_cu * ng) * std::max<int64_t>(1, -q);  // equal split: (-xth_q) segments per lane group and tile
+    } else {
+      while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
+    }
     const int xcd_group = (&M == &Xt && tune.xcd_affinity && Xt.pieces.block.size() == Xt.pieces.row.size() &&
                            !Xt.pieces.row.empty()) ? 4 * ng : 0;
     MNMF_TRY(ensure_segments(M, q, xcd_group));
@@ -546,7 +645,6 @@ class Engine : public ImplBase {
     }
     // X direction: stage the most frequent rows of the (renumbered) factor in LDS
     int hot = 0;
-    const int lds_ld = ld + VEC;
     if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= tune.hot_min_nnz &&
         (int64_t)M.tab_rows * ld * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
       hot = (int)std::min<int64_t>(M.tab_rows, tune.hot_lds_bytes / ((int64_t)lds_ld * (int64_t)sizeof(T)));

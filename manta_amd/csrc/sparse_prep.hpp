@@ -52,18 +52,79 @@ inline void pieces_from_rowptr(const int64_t* rp, int64_t rows, HostPieces& p) {
 // xcd_group > 0 (X^T with document blocks): segments are emitted so that the workgroups that share an
 // XCD (workgroup id mod 8 under round-robin dispatch; speed only, never correctness) walk the document
 // blocks b = x, x+8, ... in order, xcd_group segments per workgroup; lists are padded with empty segments.
+// Tile stream (pc.block = tile of the piece, ascending): every tile's nnz are cut into `groups` segments of equal
+// length (one per lane group of the persistent workgroup, so the groups of a tile finish together); pieces are cut
+// at segment boundaries (each part gets its own carry slot).  tile_first[t] = first segment of tile t.  Rows without
+// pieces are NOT listed as empty: they belong to the other X^T stream.
+inline void build_tile_segments_host(const HostPieces& pc, int64_t rows, int64_t n_tiles, int groups, int64_t sub,
+                                     HostSegments& s, std::vector<int32_t>& tile_first) {
+  s = HostSegments();
+  if (groups < 1) groups = 1;
+  if (sub < 1) sub = 1;
+  const int64_t np = (int64_t)pc.row.size();
+  tile_first.assign((size_t)n_tiles + 1, 0);
+  // pass 1: cut points; pass 2 needs the number of parts per row for the carry table
+  struct Part { int64_t a, b; int32_t row; };
+  std::vector<Part> parts;
+  std::vector<int64_t> seg_first_part;  // per segment: index of its first part
+  int64_t p = 0;
+  for (int64_t t = 0; t < n_tiles; ++t) {
+    tile_first[t] = (int32_t)s.seg_start.size();
+    const int64_t p0 = p;
+    while (p < np && pc.block[p] == t) ++p;
+    if (p == p0) continue;
+    const int64_t a0 = pc.start[p0], b0 = pc.start[p];
+    const int64_t len = cdiv(b0 - a0, groups);
+    int64_t q = p0;
+    for (int64_t sa = a0; sa < b0; sa += len) {
+      const int64_t sb = std::min(sa + len, b0);
+      s.seg_start.push_back(sa);
+      s.seg_len.push_back((int32_t)(sb - sa));
+      seg_first_part.push_back((int64_t)parts.size());
+      int64_t x = sa;
+      while (x < sb) {
+        while (pc.start[q + 1] <= x) ++q;
+        const int64_t e = std::min(std::min(pc.start[q + 1], sb), x + sub);
+        parts.push_back({x, e, pc.row[q]});
+        x = e;
+      }
+    }
+  }
+  tile_first[n_tiles] = (int32_t)s.seg_start.size();
+  std::vector<int32_t> cnt((size_t)rows, 0), first((size_t)rows, 0), used((size_t)rows, 0);
+  for (const Part& pt : parts) ++cnt[pt.row];
+  for (int64_t r = 0; r < rows; ++r)
+    if (cnt[r] > 1) {
+      first[r] = (int32_t)s.n_carry;
+      s.fix_row.push_back((int32_t)r);
+      s.fix_first.push_back((int32_t)s.n_carry);
+      s.fix_count.push_back(cnt[r]);
+      s.n_carry += cnt[r];
+    }
+  s.dest.reserve(parts.size());
+  s.piece_end.reserve(parts.size());
+  for (const Part& pt : parts) {
+    s.dest.push_back(cnt[pt.row] > 1 ? ~(first[pt.row] + used[pt.row]++) : pt.row);
+    s.piece_end.push_back(pt.b - 1);
+  }
+  s.seg_info.resize(seg_first_part.size());
+  for (size_t i = 0; i < seg_first_part.size(); ++i) s.seg_info[i] = (int32_t)seg_first_part[i];
+}
+
+// tile_first != nullptr: legacy tile mode (segments of about seg_nnz closed at tile boundaries, stream order).
 inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_nnz, int64_t sub, HostSegments& s,
-                                int xcd_group = 0) {
+                                int xcd_group = 0, std::vector<int32_t>* tile_first = nullptr, int64_t n_tiles = 0) {
   s = HostSegments();
   if (seg_nnz < 1) seg_nnz = 1;
   if (sub < 1) sub = 1;
   const int64_t np = (int64_t)pc.row.size();
-  const bool blocked = xcd_group > 0 && pc.block.size() == pc.row.size();
+  const bool tiled = tile_first != nullptr && pc.block.size() == pc.row.size();
+  const bool blocked = (xcd_group > 0 || tiled) && pc.block.size() == pc.row.size();
   std::vector<int32_t> cnt((size_t)rows, 0);
   for (int64_t p = 0; p < np; ++p) cnt[pc.row[p]] += (int32_t)cdiv(pc.start[p + 1] - pc.start[p], sub);
   std::vector<int32_t> first((size_t)rows, 0);
   for (int64_t r = 0; r < rows; ++r) {
-    if (cnt[r] == 0) s.empty_rows.push_back((int32_t)r);
+    if (cnt[r] == 0 && !tiled) s.empty_rows.push_back((int32_t)r);
     if (cnt[r] > 1) {
       first[r] = (int32_t)s.n_carry;
       s.fix_row.push_back((int32_t)r);
@@ -101,6 +162,16 @@ inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_
     }
   }
   if (cur >= 0) s.seg_len.push_back((int32_t)(pc.start[np] - cur));
+  if (tiled) {
+    tile_first->assign((size_t)n_tiles + 1, 0);
+    const int64_t ns = s.n_seg();
+    int64_t i = 0;
+    for (int64_t t = 0; t <= n_tiles; ++t) {
+      while (i < ns && seg_block[i] < t) ++i;
+      (*tile_first)[t] = (int32_t)i;
+    }
+    return;
+  }
   if (!blocked) return;
   // ---- XCD-affine order
   constexpr int kXcd = 8;
@@ -176,16 +247,23 @@ __global__ void col_histogram_kernel(const uint32_t* __restrict__ cols, int64_t 
   if (p < nnz) atomicAdd(&df[cols[p]], 1);   // integer counts: order-independent
 }
 
-// Sort key of nnz p for the transposed stream: (document block, vocabulary id); vocabulary rows with at
-// most `long_df` nnz are not blocked (pseudo-block n_blocks), so they stay one piece.
+// Sort key of nnz p for the transposed streams.  Words below n_hot (the most frequent ones after the engine's
+// renumbering) go to the TILE stream: key = tile * n_hot + word with tile = document / tile_rows, all below hot_span.
+// The others: hot_span + (document block, word); vocabulary rows with at most `long_df` nnz are not blocked
+// (pseudo-block n_blocks), so they stay one piece.
 __global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rowid,
                                      const int32_t* __restrict__ df, int64_t nnz, int64_t V, int block_shift,
-                                     uint32_t n_blocks, int32_t long_df, uint32_t* __restrict__ key) {
+                                     uint32_t n_blocks, int32_t long_df, uint32_t n_hot, uint32_t tile_rows,
+                                     uint32_t hot_span, uint32_t* __restrict__ key) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nnz) return;
   const uint32_t c = cols[p];
+  if (c < n_hot) {
+    key[p] = (rowid[p] / tile_rows) * n_hot + c;
+    return;
+  }
   const uint32_t b = df[c] > long_df ? (rowid[p] >> block_shift) : n_blocks;
-  key[p] = (uint32_t)((uint64_t)b * (uint64_t)V + c);
+  key[p] = hot_span + (uint32_t)((uint64_t)b * (uint64_t)V + c);
 }
 
 // flag[p] = 1 where a new piece starts (key differs from the previous nnz).
@@ -222,15 +300,23 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32
   if (i < n) out[i] = src[idx[i]];
 }
 
+// sorted position i <- original nnz perm[i]; the first n_hot_nnz positions are the TILE stream (gather index local
+// to the tile), the rest the blocked stream
 template <typename T>
 __global__ void gather_transposed_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowid,
-                                         const T* __restrict__ vals, int64_t nnz, uint32_t* __restrict__ t_cols,
-                                         T* __restrict__ t_vals) {
+                                         const T* __restrict__ vals, int64_t nnz, int64_t n_hot_nnz, uint32_t tile_rows,
+                                         uint32_t* __restrict__ h_cols, T* __restrict__ h_vals,
+                                         uint32_t* __restrict__ t_cols, T* __restrict__ t_vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
   const uint32_t p = perm[i];
-  t_cols[i] = rowid[p];
-  t_vals[i] = vals[p];
+  if (i < n_hot_nnz) {
+    h_cols[i] = rowid[p] % tile_rows;
+    h_vals[i] = vals[p];
+  } else {
+    t_cols[i - n_hot_nnz] = rowid[p];
+    t_vals[i - n_hot_nnz] = vals[p];
+  }
 }
 
 }  // namespace mnmf

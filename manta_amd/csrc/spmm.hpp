@@ -25,6 +25,10 @@
 #define MNMF_NT_LOAD(p) (*(p))
 #endif
 
+#ifndef MNMF_TILE_CH
+#define MNMF_TILE_CH 32   // nnz per stream chunk in the TILE mode (prefetch distance)
+#endif
+
 namespace mnmf {
 
 template <typename T>
@@ -42,9 +46,16 @@ struct SpmmArgs {
   T* out;
   T* carry;
   int hot_rows;              // HOT: first rows of B staged in LDS
-  int lds_ld;                // HOT: LDS row stride (elements)
+  int lds_ld;                // HOT / TILE: LDS row stride (elements)
   uint32_t tab_bytes;        // bytes of B (non-WIDE: < 4 GiB)
+  // TILE: the stream is cut into tiles of tile_rows consecutive rows of B; gather indices are local to the tile
+  const int32_t* tile_first; // [n_tiles + 1] first segment of each tile
+  int n_tiles;
+  int tile_rows;
+  int64_t tab_rows;          // rows of B
 };
+
+enum SpmmMode { SPMM_PLAIN = 0, SPMM_HOT = 1, SPMM_TILE = 2 };
 
 // The inner loop is written for a low instruction count per nnz (the gather of 16 B per lane is the
 // only memory instruction per step): 32-bit offsets, one v_mad_u32_u24 per gather address (it ignores
@@ -58,13 +69,22 @@ struct SpmmArgs {
 // document-frequency renumbering -- in LDS (row stride lds_ld, 16 B of padding against bank conflicts).
 // Hot rows are read from LDS; only the lanes of cold rows issue the buffer load (an out-of-range offset
 // instead of the exec mask was measured to cost the full vector-memory time).
-template <typename T, int LPR, int VPL, int DIR, bool HOT, bool WIDE>
-__global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
+// TILE (X^T.W for the most frequent words): persistent like HOT, but the workgroup walks tiles of tile_rows
+// consecutive rows of B (documents): it stages the tile in LDS, then its lane groups process the tile's segments,
+// whose gather indices are local to the tile -- every gather is an LDS read, the vector-memory path only carries
+// the nnz stream and the carry stores.  Profiling showed both SpMMs bound by the texture-addresser (TA busy
+// 80-93 %), which this takes out of the picture for about half of the nnz.
+template <typename T, int LPR, int VPL, int DIR, int MODE, bool WIDE>
+__global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
+  constexpr bool HOT = MODE == SPMM_HOT;
+  constexpr bool TILE = MODE == SPMM_TILE;
   constexpr int VEC = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
   using U4 = __attribute__((ext_vector_type(4))) unsigned int;
   constexpr int NG = kWave / LPR;
-  constexpr int CH = LPR < 16 ? 16 : LPR;  // steps per chunk
+  // steps per chunk.  The next chunk of (index, value) is fetched while this one is processed; a step of the TILE
+  // mode is an LDS read (tens of cycles), so its chunks are long enough to cover a trip to memory.
+  constexpr int CH = (MODE == SPMM_TILE) ? LPR * (MNMF_TILE_CH / LPR > 8 ? 8 : (MNMF_TILE_CH / LPR < 1 ? 1 : MNMF_TILE_CH / LPR)) : (LPR < 16 ? 16 : LPR);
   constexpr int EPL = CH / LPR;            // chunk elements held per lane
   constexpr int U = VPL == 2 ? 4 : 8;      // gathers in flight per batch
   static_assert(CH % U == 0, "U must divide CH");
@@ -94,16 +114,33 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
   const uint32_t rowbytes = (uint32_t)ld * (uint32_t)sizeof(T);
   const uint32_t lds_rowbytes = (uint32_t)a.lds_ld * (uint32_t)sizeof(T);
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.B), 0, WIDE ? 0u : a.tab_bytes, 0x00020000);
-  const int64_t n_waves = (a.n_seg + NG - 1) / NG;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t wave_stride = HOT ? ((int64_t)gridDim.x * blockDim.x) >> 6 : n_waves;
+  const int64_t n_outer = TILE ? a.n_tiles : 1;
+  for (int64_t tile = TILE ? blockIdx.x : 0; tile < n_outer; tile += TILE ? gridDim.x : 1) {
+  int64_t seg_lo = 0, seg_hi = a.n_seg;
+  if (TILE) {
+    __syncthreads();  // every wave is done with the previous tile
+    const int64_t r0 = tile * a.tile_rows;
+    const int nrow = (int)((a.tab_rows - r0 < a.tile_rows) ? a.tab_rows - r0 : a.tile_rows);
+    const int nvr = ld / VEC;
+    const T* src = a.B + r0 * ld;
+    for (int i = threadIdx.x; i < nrow * nvr; i += blockDim.x) {
+      const int r = i / nvr, c = (i - r * nvr) * VEC;
+      *reinterpret_cast<VT*>(lds + (size_t)r * a.lds_ld + c) = *reinterpret_cast<const VT*>(src + (size_t)r * ld + c);
+    }
+    __syncthreads();
+    seg_lo = a.tile_first[tile];
+    seg_hi = a.tile_first[tile + 1];
+  }
+  const int64_t n_waves = (seg_hi - seg_lo + NG - 1) / NG;
+  const int64_t wave0 = TILE ? (int64_t)(threadIdx.x >> 6) : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave_stride = TILE ? (int64_t)(blockDim.x >> 6) : HOT ? ((int64_t)gridDim.x * blockDim.x) >> 6 : n_waves;
   for (int64_t wave = wave0; wave < n_waves; wave += wave_stride) {
-    const int64_t seg = wave * NG + gi;
+    const int64_t seg = seg_lo + wave * NG + gi;
     const uint32_t* cp = a.cols;
     const T* vp = a.vals;
     int rem = 0;  // nnz left in this group's segment
     int j = 0;    // index of the current piece in dest[]
-    if (seg < a.n_seg) {
+    if (seg < seg_hi) {
       const int64_t s0 = a.seg_start[seg];
       cp += s0;
       vp += s0;
@@ -146,6 +183,14 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
         dl[x] = (rem > 0 && q < a.n_dest) ? a.dest[q] : 0;
       }
       const int jbase = j;
+      // end-of-piece flags of the whole chunk as wave-level bit masks (bit = holder lane): the per-step
+      // "did any group finish a piece" test is then scalar work
+      uint64_t em[EPL];
+#pragma unroll
+      for (int x = 0; x < EPL; ++x) em[x] = __ballot((int)cl[x] < 0);
+      uint64_t gmask = 0;  // bit 0 of every lane group
+#pragma unroll
+      for (int g = 0; g < NG; ++g) gmask |= (uint64_t)1 << (g * LPR);
       static_for<CH / U>([&](auto ib) {
         constexpr int u0 = decltype(ib)::value * U;
         uint32_t c[U];
@@ -164,6 +209,13 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
             const T* bp = a.B + (int64_t)(c[u] & ~kEndFlag) * ld;
 #pragma unroll
             for (int w = 0; w < VPL; ++w) b[u][w] = *reinterpret_cast<const VT*>(reinterpret_cast<const char*>(bp) + cbytes[w]);
+          } else if (TILE) {
+            const uint32_t lrow = __umul24(c[u], lds_rowbytes);  // u24: the flag bit drops out
+#pragma unroll
+            for (int w = 0; w < VPL; ++w) {
+              const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + cbytes[w]);
+              __builtin_memcpy(&b[u][w], &l, sizeof(VT));
+            }
           } else if (HOT) {
             // hot rows: LDS read (always issued, cold lanes read row 0); cold rows: buffer load under the
             // exec mask of the cold lanes only, into registers of its own (no load waits on another)
@@ -198,12 +250,10 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
           for (int w = 0; w < VPL; ++w)
 #pragma unroll
             for (int x = 0; x < VEC; ++x) acc[w][x] += v[u] * b[u][w].v[x];
-#if MNMF_ABLATE == 3   // timing experiment only: no end-of-piece handling
-          const bool endf = false;
-#else
-          const bool endf = (c[u] & kEndFlag) != 0;
-#endif
-          if (__any(endf)) {  // wave-uniform: some group finished a piece at this step
+          const int t = u0 + u;  // step in the chunk: held by lane t / EPL of each group, register t % EPL
+          const uint64_t eb = em[t % EPL] >> (t / EPL);
+          if (eb & gmask) {  // wave-uniform, scalar: some group finished a piece at this step
+            const bool endf = (eb >> gbase) & 1;
             const int idx = j - jbase;  // < CH
             int d = shfl_i(dl[0], gbase + (idx % LPR));
 #pragma unroll
@@ -240,6 +290,7 @@ __global__ __launch_bounds__(HOT ? 1024 : 256) void spmm_stream_kernel(const Spm
       }
     }
   }
+  }  // tiles
 }
 
 // One wave per chunked row: out[row] = sum of its carry slots in a fixed order.

@@ -151,14 +151,20 @@ def test_diff_norms(engines, dtype):
 
 @pytest.fixture(scope="module")
 def hot_engines():
-    """Engines forced onto the LDS-staged persistent SpMM path (normally used only for large matrices),
-    with an LDS budget small enough that hot and cold rows both occur."""
+    """Engines forced onto the LDS-staged persistent SpMM paths (normally used only for large matrices):
+    hot rows of H^T for X.H^T with an LDS budget small enough that hot and cold rows both occur, and the
+    tile stream of X^T.W (40 most frequent words, W tiles of a few hundred documents)."""
     import os
     from manta_amd.engine import Engine
 
-    old = {k_: os.environ.get(k_) for k_ in ("MNMF_HOT_MIN_NNZ", "MNMF_HOT_LDS_BYTES")}
+    old = {k_: os.environ.get(k_) for k_ in ("MNMF_HOT_MIN_NNZ", "MNMF_HOT_LDS_BYTES", "MNMF_TILE_LDS_BYTES", "MNMF_XT_HOT_WORDS",
+                                             "MNMF_TILE_MIN_ROWS", "MNMF_TILE_MIN_TILES_PER_CU")}
     os.environ["MNMF_HOT_MIN_NNZ"] = "0"
     os.environ["MNMF_HOT_LDS_BYTES"] = "20000"
+    os.environ["MNMF_TILE_LDS_BYTES"] = "40000"
+    os.environ["MNMF_XT_HOT_WORDS"] = "40"
+    os.environ["MNMF_TILE_MIN_ROWS"] = "64"
+    os.environ["MNMF_TILE_MIN_TILES_PER_CU"] = "0"
     try:
         e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
     finally:
