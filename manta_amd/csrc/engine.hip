@@ -585,7 +585,11 @@ class Engine : public ImplBase {
     const int32_t* ff = M.fix_first.template as<int32_t>();
     const int32_t* fc = M.fix_count.template as<int32_t>();
     if (M.n_fix_long > 0) {
-      spmm_fixup_long_kernel<T, LPR, VPL><<<(unsigned)M.n_fix_long, 256, 0, st()>>>(fr, ff, fc, M.carry.template as<T>(), ld, out);
+      // few rows with very long lists (tile stream): 16 waves per row; many rows with moderate lists: 4
+      if (M.n_fix_long <= (int64_t)8 * n_cus)
+        spmm_fixup_long_kernel<T, LPR, VPL, 16><<<(unsigned)M.n_fix_long, 1024, 0, st()>>>(fr, ff, fc, M.carry.template as<T>(), ld, out);
+      else
+        spmm_fixup_long_kernel<T, LPR, VPL, 4><<<(unsigned)M.n_fix_long, 256, 0, st()>>>(fr, ff, fc, M.carry.template as<T>(), ld, out);
       E_LAUNCH();
     }
     if (M.n_fix > M.n_fix_long) {

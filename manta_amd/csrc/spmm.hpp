@@ -347,11 +347,11 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t* __restri
   }
 }
 
-// One 256-thread block per row with a long carry list (hot words own thousands of segments): the 4*NG lane
-// groups stride the list, the groups of a wave are folded by shuffles and the four waves through LDS in wave
+// One block of NW waves per row with a long carry list (hot words own thousands of segments): the NW*NG lane
+// groups stride the list, the groups of a wave are folded by shuffles and the NW waves through LDS in wave
 // order -- a fixed summation tree, so the result does not depend on timing.
-template <typename T, int LPR, int VPL>
-__global__ __launch_bounds__(256) void spmm_fixup_long_kernel(const int32_t* __restrict__ fix_row,
+template <typename T, int LPR, int VPL, int NW>
+__global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t* __restrict__ fix_row,
                                                               const int32_t* __restrict__ fix_first,
                                                               const int32_t* __restrict__ fix_count,
                                                               const T* __restrict__ carry, int ld,
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_long_kernel(const int32_t* __r
   constexpr int VEC = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
   constexpr int NG = kWave / LPR;
-  __shared__ T part[4][LPR * VPL * VEC];
+  __shared__ T part[NW][LPR * VPL * VEC];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gi = lane / LPR, li = lane % LPR;
   const int64_t item = blockIdx.x;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_long_kernel(const int32_t* __r
 #pragma unroll
     for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
 #pragma unroll 4
-  for (int s = wv * NG + gi; s < n; s += 4 * NG) {
+  for (int s = wv * NG + gi; s < n; s += NW * NG) {
     const T* cp = carry + (first + s) * ld;
 #pragma unroll
     for (int w = 0; w < VPL; ++w) {
@@ -404,7 +404,12 @@ __global__ __launch_bounds__(256) void spmm_fixup_long_kernel(const int32_t* __r
       if (co < ld) {
         VT o;
 #pragma unroll
-        for (int x = 0; x < VEC; ++x) o.v[x] = ((part[0][co + x] + part[1][co + x]) + part[2][co + x]) + part[3][co + x];
+        for (int x = 0; x < VEC; ++x) {
+          T t = part[0][co + x];
+#pragma unroll
+          for (int w2 = 1; w2 < NW; ++w2) t += part[w2][co + x];
+          o.v[x] = t;
+        }
         *reinterpret_cast<VT*>(op + co) = o;
       }
     }
