@@ -159,6 +159,13 @@ int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, in
 int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
                                int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece,
                                int xcd_group, mnmf_segments* out);
+/* Tile stream of X^T (the most frequent words; DESIGN.md "tile stream"): piece_tile[i] = tile of piece i,
+ * ascending.  seg_nnz > 0: segments of about seg_nnz nnz that never cross a tile; seg_nnz <= 0: every tile is cut
+ * into -seg_nnz equal segments (pieces are cut at segment boundaries).  tile_first (n_tiles + 1 entries, caller
+ * allocated) receives the first segment of each tile.  Rows without pieces are not reported as empty. */
+int mnmf_build_segments_tiles(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_tile,
+                              int64_t n_pieces, int64_t rows, int64_t n_tiles, int64_t seg_nnz, int64_t sub_piece,
+                              mnmf_segments* out, int32_t* tile_first);
 void mnmf_free_segments(mnmf_segments* s);
 /* lambda_max of a symmetric n x n matrix (row-major, double) by cyclic Jacobi. */
 double mnmf_sym_lambda_max(const double* a, int n);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mnmf_build_segments": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(MnmfSegments)]),
     "mnmf_build_segments_pieces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int64, C.c_int, C.POINTER(MnmfSegments)]),
+    "mnmf_build_segments_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                            C.c_int64, C.c_int64, C.POINTER(MnmfSegments), C.c_void_p]),
     "mnmf_free_segments": (None, [C.POINTER(MnmfSegments)]),
     "mnmf_sym_lambda_max": (C.c_double, [C.c_void_p, C.c_int]),
 }

@@ -1508,6 +1508,29 @@ int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_
   return MNMF_OK;
 }
 
+int mnmf_build_segments_tiles(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_tile,
+                              int64_t n_pieces, int64_t rows, int64_t n_tiles, int64_t seg_nnz, int64_t sub_piece,
+                              mnmf_segments* out, int32_t* tile_first) {
+  if (!piece_start || !out || !tile_first || rows < 0 || n_pieces < 0 || n_tiles < 0 || (n_pieces > 0 && (!piece_row || !piece_tile)))
+    return MNMF_EINVAL;
+  HostPieces pc;
+  pc.start.assign(piece_start, piece_start + n_pieces + 1);
+  pc.row.assign(piece_row, piece_row + n_pieces);
+  pc.block.assign(piece_tile, piece_tile + n_pieces);
+  for (int64_t i = 0; i < n_pieces; ++i)
+    if (pc.row[i] < 0 || pc.row[i] >= rows || pc.start[i + 1] <= pc.start[i] || pc.block[i] < 0 || pc.block[i] >= n_tiles ||
+        (i > 0 && pc.block[i] < pc.block[i - 1]))
+      return MNMF_EINVAL;
+  HostSegments s;
+  std::vector<int32_t> tf;
+  if (seg_nnz <= 0) build_tile_segments_host(pc, rows, n_tiles, (int)std::max<int64_t>(1, -seg_nnz), sub_piece, s, tf);
+  else build_segments_host(pc, rows, seg_nnz, sub_piece, s, 0, &tf, n_tiles);
+  tf.resize((size_t)n_tiles + 1, (int32_t)s.n_seg());
+  std::memcpy(tile_first, tf.data(), ((size_t)n_tiles + 1) * sizeof(int32_t));
+  export_segments(s, out);
+  return MNMF_OK;
+}
+
 void mnmf_free_segments(mnmf_segments* s) {
   if (!s) return;
   std::free(s->seg_start);

@@ -111,7 +111,8 @@ inline void build_tile_segments_host(const HostPieces& pc, int64_t rows, int64_t
   for (size_t i = 0; i < seg_first_part.size(); ++i) s.seg_info[i] = (int32_t)seg_first_part[i];
 }
 
-// tile_first != nullptr: legacy tile mode (segments of about seg_nnz closed at tile boundaries, stream order).
+// tile_first != nullptr (tile stream, the default mode): segments of about seg_nnz nnz that are closed at tile
+// boundaries and stay in stream order; tile_first[t] = first segment of tile t; no empty-row list.
 inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_nnz, int64_t sub, HostSegments& s,
                                 int xcd_group = 0, std::vector<int32_t>* tile_first = nullptr, int64_t n_tiles = 0) {
   s = HostSegments();

@@ -244,12 +244,22 @@ class Engine:
 
 
 def build_segments(rowptr=None, seg_nnz=64, sub_piece=512, *, piece_start=None, piece_row=None, piece_block=None,
-                   rows=None, xcd_group=0):
+                   rows=None, xcd_group=0, n_tiles=None):
     """Host-only: the segment description the engine builds (no GPU needed; used by CPU tests).
-    Give a CSR ``rowptr`` (one piece per non-empty row) or explicit pieces in processing order."""
+    Give a CSR ``rowptr`` (one piece per non-empty row) or explicit pieces in processing order.
+    With ``n_tiles`` the pieces describe the tile stream of X^T (``piece_block`` = tile of each piece) and the
+    result also holds ``tile_first``; ``seg_nnz <= 0`` then means -seg_nnz equal segments per tile."""
     lib = _lib.load()
     s = _lib.MnmfSegments()
-    if rowptr is not None:
+    tile_first = None
+    if n_tiles is not None:
+        ps = np.ascontiguousarray(piece_start, dtype=np.int64)
+        pr = np.ascontiguousarray(piece_row, dtype=np.int32)
+        pb = np.ascontiguousarray(piece_block, dtype=np.int32)
+        tile_first = np.zeros(int(n_tiles) + 1, np.int32)
+        rc = lib.mnmf_build_segments_tiles(ps.ctypes.data, pr.ctypes.data, pb.ctypes.data, len(pr), int(rows), int(n_tiles),
+                                           int(seg_nnz), int(sub_piece), C.byref(s), tile_first.ctypes.data)
+    elif rowptr is not None:
         rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         rc = lib.mnmf_build_segments(rp.ctypes.data, len(rp) - 1, int(seg_nnz), int(sub_piece), C.byref(s))
     else:
@@ -264,7 +274,8 @@ def build_segments(rowptr=None, seg_nnz=64, sub_piece=512, *, piece_start=None, 
     try:
         def arr(p, n, dt):
             return np.ctypeslib.as_array(p, shape=(max(int(n), 1),))[: int(n)].astype(dt).copy()
-        return dict(seg_start=arr(s.seg_start, s.n_seg, np.int64), seg_len=arr(s.seg_len, s.n_seg, np.int32),
+        extra = {} if tile_first is None else {"tile_first": tile_first}
+        return dict(**extra, seg_start=arr(s.seg_start, s.n_seg, np.int64), seg_len=arr(s.seg_len, s.n_seg, np.int32),
                     seg_info=arr(s.seg_info, s.n_seg, np.int32),
                     dest=arr(s.dest, s.n_dest, np.int32), piece_end=arr(s.piece_end, s.n_dest, np.int64),
                     empty_rows=arr(s.empty_rows, s.n_empty, np.int32),

@@ -131,6 +131,46 @@ def test_segments_blocked_pieces():
             assert np.all(np.diff(sl) >= 0) and sl.min() == first and sl.max() == first + cnt - 1
 
 
+@pytest.mark.parametrize("seg_nnz", [96, 17, -4, -64])
+def test_segments_tile_stream(seg_nnz):
+    """Tile stream of X^T: every hot word has one piece per tile; segments never cross a tile, tile_first indexes
+    them, equal-split mode cuts every tile into the requested number of segments."""
+    from manta_amd.engine import build_segments
+
+    rng = np.random.RandomState(11)
+    n_hot, n_tiles = 12, 9
+    rows, lens, tiles = [], [], []
+    for t in range(n_tiles):
+        if t == 4:
+            continue                          # a tile without any hot nnz
+        for r in range(n_hot):
+            if r == 7 and t != 2:
+                continue                      # a word present in one tile only: a direct row, no carries
+            if rng.rand() < 0.9:
+                rows.append(r)
+                lens.append(int(rng.randint(1, 900)))
+                tiles.append(t)
+    start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    truth = np.repeat(np.array(rows), lens)
+    tile_of_nnz = np.repeat(np.array(tiles), lens)
+    seg = build_segments(piece_start=start, piece_row=np.array(rows), piece_block=np.array(tiles), rows=40,
+                         seg_nnz=seg_nnz, sub_piece=512, n_tiles=n_tiles)
+    seg_plain = dict(seg, empty_rows=np.nonzero(~np.isin(np.arange(40), truth))[0].astype(np.int32))  # not reported
+    assert len(seg["empty_rows"]) == 0
+    _check_cover(seg_plain, truth, 40, 512)
+    tf = seg["tile_first"]
+    assert tf[0] == 0 and tf[-1] == len(seg["seg_len"]) and np.all(np.diff(tf) >= 0)
+    assert tf[5] == tf[4], "an empty tile owns no segment"
+    for t in range(n_tiles):
+        for s_i in range(tf[t], tf[t + 1]):
+            a, b = seg["seg_start"][s_i], seg["seg_start"][s_i] + seg["seg_len"][s_i]
+            assert np.all(tile_of_nnz[a:b] == t)
+        if seg_nnz <= 0 and tf[t + 1] > tf[t]:
+            ln = seg["seg_len"][tf[t]:tf[t + 1]]
+            assert len(ln) <= -seg_nnz and ln.max() - ln.min() <= ln.max() - ln[-1] and np.all(ln[:-1] == ln[0])
+    assert seg["seg_len"].sum() == start[-1]
+
+
 def test_segments_degenerate():
     from manta_amd.engine import build_segments
 
