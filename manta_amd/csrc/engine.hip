@@ -294,6 +294,20 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  // df[c] = number of nnz in column c of X (end flags must be clear)
+  int column_histogram(int32_t* df) {
+    const int copies = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)64 << 20) / std::max<int64_t>(V * 4, 1)));
+    DevBuf parts;
+    E_HIP(parts.ensure((size_t)copies * V * 4));
+    E_HIP(hipMemsetAsync(parts.p, 0, (size_t)copies * V * 4, st()));
+    col_histogram_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, parts.template as<int32_t>(), V, copies);
+    E_LAUNCH();
+    col_histogram_sum_kernel<<<(unsigned)cdiv(V, 256), 256, 0, st()>>>(parts.template as<int32_t>(), V, copies, df);
+    E_LAUNCH();
+    E_HIP(hipStreamSynchronize(st()));  // parts is freed at scope exit
+    return 0;
+  }
+
   int clear_x_flags() {
     if (X.flags_set && nnz > 0) {
       clear_flags_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, st()>>>(X.cols.template as<uint32_t>(), nnz);
@@ -319,9 +333,7 @@ class Engine : public ImplBase {
     E_HIP(d_newid.ensure((size_t)V * 4));
     E_HIP(d_order.ensure((size_t)V * 4));
     MNMF_TRY(clear_x_flags());
-    E_HIP(hipMemsetAsync(df.p, 0, (size_t)V * 4, st()));
-    col_histogram_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, df.template as<int32_t>());
-    E_LAUNCH();
+    MNMF_TRY(column_histogram(df.template as<int32_t>()));
     df_to_key_kernel<T><<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(df.template as<int32_t>(), V, key.template as<T>(), iota.template as<uint32_t>());
     E_LAUNCH();
     MNMF_TRY(allreduce(key.template as<T>(), V));
@@ -388,8 +400,7 @@ class Engine : public ImplBase {
     expand_rowids_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(d_rowptr.template as<int64_t>(), m, nnz,
                                                                    rowid.template as<uint32_t>(), iota.template as<uint32_t>());
     E_LAUNCH();
-    col_histogram_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, df.template as<int32_t>());
-    E_LAUNCH();
+    MNMF_TRY(column_histogram(df.template as<int32_t>()));
     int64_t n_hot_nnz = 0;
     if (n_hot > 0) {  // nnz of the tile stream = sum of the first n_hot document frequencies
       size_t bytes = 0;
