@@ -173,6 +173,7 @@ class Engine : public ImplBase {
   }
   ~Engine() override {
     if (h_pinned) (void)hipHostFree(h_pinned);
+    if (ev_fetch) (void)hipEventDestroy(ev_fetch);
   }
 
   mnmf_ctx* ctx;
@@ -860,6 +861,32 @@ class Engine : public ImplBase {
     for (size_t i = 0; i < cnt; ++i) out[i] = (double)hp[i];
     return 0;
   }
+  // Split-phase variant: the copies are enqueued behind the kernels that produce the data, the host reads them
+  // later (after it has enqueued more work), so the GPU never idles while the host looks at the norms.
+  size_t fetch_count = 0;
+  hipEvent_t ev_fetch = nullptr;
+  int fetch_begin(size_t max_elems) {
+    MNMF_TRY(pinned(max_elems));
+    fetch_count = 0;
+    if (!ev_fetch) E_HIP(hipEventCreateWithFlags(&ev_fetch, hipEventDisableTiming));
+    return 0;
+  }
+  int fetch_add(const T* d, size_t cnt) {
+    E_HIP(hipMemcpyAsync(reinterpret_cast<T*>(h_pinned) + fetch_count, d, cnt * sizeof(T), hipMemcpyDeviceToHost, st()));
+    fetch_count += cnt;
+    return 0;
+  }
+  int fetch_commit() {
+    E_HIP(hipEventRecord(ev_fetch, st()));
+    return 0;
+  }
+  int fetch_end(std::vector<double>& out) {
+    E_HIP(hipEventSynchronize(ev_fetch));
+    out.resize(fetch_count);
+    const T* hp = reinterpret_cast<const T*>(h_pinned);
+    for (size_t i = 0; i < fetch_count; ++i) out[i] = (double)hp[i];
+    return 0;
+  }
   static double spectral_from_gram(const double* g, int ld) { return std::sqrt(std::max(0.0, nonneg_lambda_max(g, ld))); }
   static double fro_from_gram(const double* g, int ld) {
     double t = 0.0;
@@ -972,6 +999,20 @@ class Engine : public ImplBase {
     PhaseTimer pt(st(), o && o->profile_phases);
     pt.mark(-1);
     std::vector<double> g;
+    // The norms of iteration i are read while iteration i+1's SpMMs are already queued (its H update only writes
+    // the buffer of h_{i-1}); if iteration i turns out to have converged, that queued work is simply dropped.
+    bool pending = false;
+    int64_t done = 0;  // completed iterations
+    auto resolve = [&]() -> int {
+      MNMF_TRY(fetch_end(g));
+      pending = false;
+      w_norm = spectral_from_gram(g.data(), ld);
+      h_norm = spectral_from_gram(g.data() + (size_t)ld * ld, ld);
+      if (!std::isfinite(w_norm) || !std::isfinite(h_norm))
+        return fail(MNMF_ENAN, "nmf: non-finite update norm at iteration " + std::to_string(done));
+      return 0;
+    };
+    MNMF_TRY(pinned(2 * (size_t)ld * ld));
     while (true) {
       T* Wc = Wb[cw].template as<T>();
       T* Wn = Wb[1 - cw].template as<T>();
@@ -988,36 +1029,47 @@ class Engine : public ImplBase {
       pt.mark(2);
       MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                            // in_mat @ h.T         :45
       pt.mark(4);
+      if (pending) {  // norms of the previous iteration                 :52-53, :62
+        const int r = resolve();
+        pt.mark(6);
+        if (r != 0) {
+          (void)clock_stop(clk, stats);
+          return r;
+        }
+        if (fixed <= 0 && w_norm < thr && h_norm < thr) {
+          converged = 1;
+          break;
+        }
+      }
       // w update :46-47, with the next iteration's wT_w (:39) and D^T D of D = |w - w_old| (:52)
       MNMF_TRY(rk_grams(RK_MU, Wc, Gh, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw, do_check ? Gd : nullptr));
       gw_valid = true;
       pt.mark(5);
       if (do_check) {
         MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
-        MNMF_TRY(fetch_grams(Gd, 2, ld, g));
-        w_norm = spectral_from_gram(g.data(), ld);
-        h_norm = spectral_from_gram(g.data() + (size_t)ld * ld, ld);
+        MNMF_TRY(fetch_begin(2 * (size_t)ld * ld));
+        MNMF_TRY(fetch_add(Gd, 2 * (size_t)ld * ld));
+        MNMF_TRY(fetch_commit());
+        pending = true;
         pt.mark(6);
-        if (!std::isfinite(w_norm) || !std::isfinite(h_norm)) {
-          cw = 1 - cw;
-          ch = 1 - ch;
-          ++i;
-          (void)clock_stop(clk, stats);
-          return fail(MNMF_ENAN, "nmf: non-finite update norm at iteration " + std::to_string(i));
-        }
       }
       cw = 1 - cw;
       ch = 1 - ch;
+      ++done;
       if (fixed > 0) {
         if (i + 1 >= fixed) break;
       } else {
         if (i >= max_iter) break;                                      // :57
-        if (do_check && w_norm < thr && h_norm < thr) {                // :62
-          converged = 1;
-          break;
-        }
       }
       ++i;
+    }
+    if (pending) {  // the last iteration's norms (the loop ended on its iteration cap)
+      const int r = resolve();
+      if (r != 0) {
+        (void)clock_stop(clk, stats);
+        return r;
+      }
+      if (fixed <= 0 && done <= max_iter && w_norm < thr && h_norm < thr) converged = 1;   // :57 comes before :62
     }
     MNMF_TRY(clock_stop(clk, stats));
     pt.collect(phase_ms);
@@ -1026,7 +1078,7 @@ class Engine : public ImplBase {
     MNMF_TRY(store_H(Hb[ch].template as<T>(), k, ld, finalize ? zthr : -1.0, H));  // :87
     E_HIP(hipStreamSynchronize(st()));
     if (stats) {
-      stats->iters = (int32_t)(i + 1);
+      stats->iters = (int32_t)done;
       stats->converged = converged;
       stats->w_norm = w_norm;
       stats->h_norm = h_norm;
