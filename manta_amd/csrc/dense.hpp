@@ -269,7 +269,7 @@ __global__ void unpad_rows_kernel(const T* __restrict__ in, int64_t rows, int k,
   const int64_t r = i / k;
   const int c = (int)(i % k);
   const T v = in[(map ? (int64_t)map[r] : r) * ld + c];
-  out[i] = (v < thr) ? T(0) : v;
+  out[i] = (thr > T(0) && v < thr) ? T(0) : v;
 }
 
 // H (k x V row-major) -> Ht (V x ld, zero padded), 32 x 32 tiles through LDS.
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const T* __restrict_
     const int64_t v = v0 + tx;
     if (c < k && v < V) {
       const T x = tile[tx][i];
-      H[(int64_t)c * V + v] = (x < thr) ? T(0) : x;
+      H[(int64_t)c * V + v] = (thr > T(0) && x < thr) ? T(0) : x;
     }
   }
 }

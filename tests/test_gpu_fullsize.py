@@ -1,0 +1,113 @@
+"""Full-size checks (BASELINE.json configs[1]: 1M docs x 100k vocab, ~0.1 % density, k = 50) through the C-ABI.
+
+The CPU oracle needs minutes per iteration at this size, so parity here rests on size-independent properties and
+on an independent float64 product (torch's sparse CSR matmul on the same device arrays):
+  * X.B and X^T.A against torch.sparse float64 (all stream variants are active at this size: LDS-hot rows of H^T,
+    the document-blocked X^T stream, the LDS tile stream of the frequent words, block-per-row fix-ups);
+  * adjointness <X.B, A> = <B, X^T.A> and linearity of both products;
+  * five NMF iterations: fp32 agrees with fp64 within the stated fp32 tolerance, the objective ||X - W.H||_F
+    never increases (the MU guarantee the reference relies on), exact zeros of the init stay exactly zero,
+    and two runs are bit-identical.
+Tolerances: fp64 1e-12, fp32 2e-6 relative Frobenius for single products; 1e-4 for the iterated factors."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M, V, DENSITY, K = 1_000_000, 100_000, 0.001, 50
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import torch
+    from manta_amd.synth import zipf_tfidf_csr
+
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = zipf_tfidf_csr(M, V, DENSITY, seed=1234, device=dev, dtype=torch.float64)
+    Xs = torch.sparse_csr_tensor(rowptr, col.long(), val, size=(M, V))
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    B = torch.rand((V, K), generator=g, device=dev, dtype=torch.float64)
+    A = torch.rand((M, K), generator=g, device=dev, dtype=torch.float64)
+    return dict(rowptr=rowptr, col=col, val=val, Xs=Xs, A=A, B=B, dev=dev)
+
+
+def _rel(a, b):
+    import torch
+    return float(torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double()))
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("fp64", 1e-12)])
+def test_products_against_torch_sparse_and_adjointness(c2, dtype, tol):
+    import torch
+    from manta_amd.engine import Engine
+
+    eng = Engine(dtype=dtype)
+    try:
+        eng.set_matrix(rowptr=c2["rowptr"], colidx=c2["col"], vals=c2["val"], shape=(M, V))
+        A, B = c2["A"].to(eng.tdtype), c2["B"].to(eng.tdtype)
+        XB = eng.spmm(B)
+        XtA = eng.spmm(A, transpose=True)
+        want_XB = c2["Xs"] @ B.double()
+        assert _rel(XB, want_XB) <= tol
+        del want_XB
+        # X^T.A in float64 without materialising X^T: column sums through index_add over the nnz
+        rows = torch.repeat_interleave(torch.arange(M, device=c2["dev"]), c2["rowptr"][1:] - c2["rowptr"][:-1])
+        want = torch.zeros((V, K), device=c2["dev"], dtype=torch.float64)
+        step = 1 << 24
+        for s in range(0, rows.numel(), step):
+            e = min(s + step, rows.numel())
+            want.index_add_(0, c2["col"][s:e].long(), A.double()[rows[s:e]] * c2["val"][s:e, None])
+        assert _rel(XtA, want) <= max(tol, 1e-12)
+        del want, rows
+        lhs = float((XB.double() * A.double()).sum())
+        rhs = float((B.double() * XtA.double()).sum())
+        assert abs(lhs - rhs) <= 10 * tol * abs(rhs)
+        B2 = torch.flip(B, dims=[0])
+        assert _rel(eng.spmm(2.0 * B - 3.0 * B2), 2.0 * XB.double() - 3.0 * eng.spmm(B2).double()) <= 10 * tol
+        assert torch.equal(eng.spmm(A, transpose=True), XtA), "X^T.A must be bit-reproducible"
+    finally:
+        eng.close()
+
+
+def test_nmf_iterations_full_size(c2):
+    import torch
+    from manta_amd.engine import Engine
+
+    dev = c2["dev"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    xmax = float(c2["val"].max())
+    H0 = torch.rand((K, V), generator=g, device=dev, dtype=torch.float64) * xmax
+    W0 = torch.rand((M, K), generator=g, device=dev, dtype=torch.float64) * xmax
+    W0[::7, 3] = 0.0                       # NNDSVD-style exact zeros must stay zero
+    H0[5, ::11] = 0.0
+    x2 = float((c2["val"] ** 2).sum())
+
+    def objective(W, H):                    # ||X - W.H||_F^2 = ||X||^2 - 2 <X.H^T, W> + <W^T W, H H^T>
+        W, H = W.double(), H.double()
+        XHt = c2["Xs"] @ H.t().contiguous()
+        return x2 - 2.0 * float((XHt * W).sum()) + float(((W.t() @ W) * (H @ H.t())).sum())
+
+    out = {}
+    for dtype in ("fp64", "fp32"):
+        eng = Engine(dtype=dtype)
+        try:
+            eng.set_matrix(rowptr=c2["rowptr"], colidx=c2["col"], vals=c2["val"], shape=(M, V))
+            objs = [objective(W0, H0)]
+            W, H = W0, H0
+            for _ in range(5):
+                W, H, st = eng.run_nmf(W, H, fixed_iters=1, force_check=True, finalize=False)
+                objs.append(objective(W, H))
+            assert all(b <= a * (1 + 1e-9) for a, b in zip(objs, objs[1:])), objs
+            W5, H5, st = eng.run_nmf(W0, H0, fixed_iters=5, force_check=True, finalize=False)
+            assert st.iters == 5 and st.w_norm > 0 and st.h_norm > 0
+            if dtype == "fp64":
+                assert _rel(W5, W) <= 1e-12 and _rel(H5, H) <= 1e-12   # one call of 5 = five calls of 1
+            assert bool((W5[::7, 3] == 0).all()) and bool((H5[5, ::11] == 0).all())
+            W5b, H5b, _ = eng.run_nmf(W0, H0, fixed_iters=5, force_check=True, finalize=False)
+            assert torch.equal(W5, W5b) and torch.equal(H5, H5b), "runs must be bit-identical"
+            out[dtype] = (W5.double(), H5.double())
+        finally:
+            eng.close()
+    assert _rel(out["fp32"][0], out["fp64"][0]) <= 1e-4
+    assert _rel(out["fp32"][1], out["fp64"][1]) <= 1e-4

@@ -67,6 +67,10 @@ def test_spmm_both_directions(engines, dtype, k):
     # rows without nnz must come out exactly 0
     out = host(eng.spmm(B))
     assert np.all(out[np.diff(X.indptr) == 0] == 0)
+    # signed operands (the solvers never produce them, the kernel-level entry points must still be exact)
+    Bs, As = B - 0.5, 3.0 * (A - 0.5)
+    assert rel(host(eng.spmm(Bs)), X @ Bs) <= TOL[dtype] * 20
+    assert rel(host(eng.spmm(As, transpose=True)), X.T @ As) <= TOL[dtype] * 20
 
 
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
