@@ -1,4 +1,5 @@
-"""Full-size checks (BASELINE.json configs[1]: 1M docs x 100k vocab, ~0.1 % density, k = 50) through the C-ABI.
+"""Full-size checks (BASELINE.json configs[1..3]; mostly configs[1]: 1M docs x 100k vocab, ~0.1 % density, k = 50)
+through the C-ABI.
 
 The CPU oracle needs minutes per iteration at this size, so parity here rests on size-independent properties and
 on an independent float64 product (torch's sparse CSR matmul on the same device arrays):
@@ -7,7 +8,9 @@ on an independent float64 product (torch's sparse CSR matmul on the same device 
   * adjointness <X.B, A> = <B, X^T.A> and linearity of both products;
   * five NMF iterations: fp32 agrees with fp64 within the stated fp32 tolerance, the objective ||X - W.H||_F
     never increases (the MU guarantee the reference relies on), exact zeros of the init stay exactly zero,
-    and two runs are bit-identical.
+    and two runs are bit-identical;
+  * two iterations of NMF (configs[1]), Projective NMF (configs[2], k = 100) and NMTF (configs[3], 2M x 200k,
+    k = 20) against a plain torch float64 restatement of the reference's update formulas.
 Tolerances: fp64 1e-12, fp32 2e-6 relative Frobenius for single products; 1e-4 for the iterated factors."""
 import pytest
 
@@ -111,3 +114,88 @@ def test_nmf_iterations_full_size(c2):
             eng.close()
     assert _rel(out["fp32"][0], out["fp64"][0]) <= 1e-4
     assert _rel(out["fp32"][1], out["fp64"][1]) <= 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# One or two iterations of each solver at the full size of its BASELINE.json config against a plain torch float64
+# restatement of the reference's update formulas (the numpy oracle needs minutes per iteration here).
+def _torch_ops(rowptr, col, val, m, V, dev):
+    import torch
+
+    Xs = torch.sparse_csr_tensor(rowptr, col.long(), val, size=(m, V))
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), rowptr[1:] - rowptr[:-1])
+
+    def x_times(B):            # X @ B
+        return Xs @ B.contiguous()
+
+    def xt_times(A):           # X.T @ A without materialising X.T
+        out = torch.zeros((V, A.shape[1]), device=dev, dtype=torch.float64)
+        step = 1 << 24
+        for s in range(0, rows.numel(), step):
+            e = min(s + step, rows.numel())
+            out.index_add_(0, col[s:e].long(), A[rows[s:e]] * val[s:e, None])
+        return out
+
+    return x_times, xt_times
+
+
+def _inits(m, V, k, xmax, dev, seed=42):
+    import torch
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    H0 = torch.rand((k, V), generator=g, device=dev, dtype=torch.float64) * xmax
+    S0 = torch.rand((k, k), generator=g, device=dev, dtype=torch.float64) * xmax
+    W0 = torch.rand((m, k), generator=g, device=dev, dtype=torch.float64) * xmax
+    return W0, S0, H0
+
+
+@pytest.mark.parametrize("method,m,V,density,k,iters", [
+    ("nmf", 1_000_000, 100_000, 0.001, 50, 2),      # configs[1]
+    ("pnmf", 1_000_000, 100_000, 0.001, 100, 2),    # configs[2]
+    ("nmtf", 2_000_000, 200_000, 0.0005, 20, 2),    # configs[3]
+])
+def test_solver_iterations_against_torch_float64_full_size(method, m, V, density, k, iters):
+    import torch
+    from manta_amd.engine import Engine
+    from manta_amd.synth import zipf_tfidf_csr
+
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = zipf_tfidf_csr(m, V, density, seed=1234, device=dev, dtype=torch.float64)
+    x_times, xt_times = _torch_ops(rowptr, col, val, m, V, dev)
+    W0, S0, H0 = _inits(m, V, k, float(val.max()), dev)
+    w, s, h = W0.clone(), S0.clone(), H0.clone()
+    for _ in range(iters):
+        if method == "nmf":                                        # nmf_basic.py:39-47, eps 1e-10
+            h = h * (xt_times(w).t() / ((w.t() @ w) @ h + 1e-10))
+            w = w * (x_times(h.t()) / (w @ (h @ h.t()) + 1e-10))
+        elif method == "pnmf":                                     # nmf_projective_basic.py:68-79
+            wtw = w.t() @ w
+            pay = x_times(xt_times(w))
+            w = w * torch.sqrt(pay / (w @ (w.t() @ pay) + pay @ wtw + 1e-10))
+        else:                                                      # nmtf.py:150-163, eps 1e-9
+            hht = h @ h.t()
+            w1 = w * (x_times(h.t() @ s.t()) / (w @ s @ hht @ s.t() + 1e-9))
+            P = xt_times(w1).t()                                   # w1.T @ X
+            g1 = w1.t() @ w1
+            s1 = s * ((P @ h.t()) / (g1 @ s @ hht + 1e-9))
+            h = h * ((s1.t() @ P) / (s1.t() @ g1 @ s1 @ h + 1e-9))
+            w, s = w1, s1
+    for dtype, tol in (("fp64", 1e-10), ("fp32", 1e-4)):
+        eng = Engine(dtype=dtype)
+        try:
+            eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(m, V))
+            kw = dict(fixed_iters=iters, force_check=True, finalize=False)
+            if method == "nmf":
+                W, H, st = eng.run_nmf(W0, H0, **kw)
+                assert _rel(W, w) <= tol and _rel(H, h) <= tol, (dtype, _rel(W, w), _rel(H, h))
+            elif method == "pnmf":
+                W, H, st = eng.run_pnmf(W0, **kw)                  # finalize=False: W after `iters` updates, H = W.T @ X
+                assert _rel(W, w) <= tol, (dtype, _rel(W, w))
+                assert _rel(H, xt_times(w).t()) <= tol
+            else:
+                W, S, H, st = eng.run_nmtf(W0, S0, H0, **kw)
+                assert _rel(W, w) <= tol and _rel(S, s) <= tol and _rel(H, h) <= tol, (dtype, _rel(W, w), _rel(S, s), _rel(H, h))
+            assert st.iters == iters
+        finally:
+            eng.close()
