@@ -83,6 +83,8 @@ struct Tune {
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 448;            // tile stream only if a tile holds at least this many documents ...
   int tile_min_tiles_per_cu = 4;      // ... and there are this many tiles per CU
+  int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
+  int tile_threads = 1024;            // threads of the tile kernel's workgroup (one per CU)
   int tile_wgs_per_cu = 1;            // workgroups per CU in the tile kernel (1, 2 or 4)
   int64_t xth_q = 96;                 // X^T tile stream: > 0 target nnz per segment; <= 0: equal split, -xth_q segments per lane group
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
@@ -104,6 +106,9 @@ struct Tune {
     xth_q = geti("MNMF_XTH_Q", xth_q);
     tile_min_rows = (int)geti("MNMF_TILE_MIN_ROWS", tile_min_rows);
     tile_min_tiles_per_cu = (int)geti("MNMF_TILE_MIN_TILES_PER_CU", tile_min_tiles_per_cu);
+    xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
+    tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
+    if (tile_threads != 256 && tile_threads != 512) tile_threads = 1024;
     tile_wgs_per_cu = (int)geti("MNMF_TILE_WGS", tile_wgs_per_cu);
     if (tile_wgs_per_cu != 2 && tile_wgs_per_cu != 4) tile_wgs_per_cu = 1;
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
@@ -174,6 +179,9 @@ class Engine : public ImplBase {
   ~Engine() override {
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
   }
 
   mnmf_ctx* ctx;
@@ -194,7 +202,10 @@ class Engine : public ImplBase {
   size_t h_pinned_cap = 0;
   double phase_ms[PhaseTimer::kMaxPhases] = {0};
 
-  hipStream_t st() const { return ctx->stream; }
+  // the caller's stream, or the engine's side stream while the X^T tile stream is being enqueued (see spmm)
+  hipStream_t side_stream = nullptr, st_override = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t st() const { return st_override ? st_override : ctx->stream; }
   // leading dimension of every factor matrix: a multiple of 4 elements; rows of more than 32 elements
   // are padded to whole 64-byte multiples (tune.ld_align elements) so a gathered row starts line-aligned.
   int ld_of(int k) const {
@@ -572,7 +583,7 @@ class Engine : public ImplBase {
         E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         a.hot_rows = 0;
         const int wgs = std::max(1, tune.tile_wgs_per_cu);  // workgroups per CU: one stages while another computes
-        kern<<<(unsigned)std::min<int64_t>((int64_t)n_cus * wgs, M.n_tiles), 1024 / wgs, lds_bytes, st()>>>(a);
+        kern<<<(unsigned)std::min<int64_t>((int64_t)n_cus * wgs, M.n_tiles), std::min(tune.tile_threads, 1024 / wgs), lds_bytes, st()>>>(a);
         E_LAUNCH();
       }
     } else if (waves > 0 && hot > 0 && !wide) {
@@ -638,12 +649,36 @@ class Engine : public ImplBase {
       }
       MNMF_TRY(ensure_xt(bs, n_hot, tile_rows));
     }
+    if (&M == &Xt && Xth.nnz > 0 && tune.xt_overlap) {
+      // The blocked stream is bound by the vector-memory path and the fabric, the tile stream by LDS and VALU
+      // issue: enqueue them on two streams so the CUs run both at once.  They write disjoint rows of `out`,
+      // except that the blocked stream first zeroes the rows it has no nnz for (the tile stream's rows among
+      // them): that happens before the fork.
+      if (!side_stream) {
+        E_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+        E_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        E_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+      }
+      MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 1));   // segments + zero rows only
+      MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
+      E_HIP(hipEventRecord(ev_fork, ctx->stream));
+      E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+      st_override = side_stream;
+      const int r = spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2);
+      st_override = nullptr;
+      MNMF_TRY(r);
+      E_HIP(hipEventRecord(ev_join, side_stream));
+      MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      E_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
+      return 0;
+    }
     MNMF_TRY(spmm_stream(M, B, ld, out, lpr, vpl, ng, lds_ld));
     if (&M == &Xt && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld));
     return 0;
   }
 
-  int spmm_stream(StreamMat<T>& M, const T* B, int ld, T* out, int lpr, int vpl, int ng, int lds_ld) {
+  // part: 0 = everything, 1 = preparation (segments, carry buffer, zeroing of empty rows), 2 = kernels only
+  int spmm_stream(StreamMat<T>& M, const T* B, int ld, T* out, int lpr, int vpl, int ng, int lds_ld, int part = 0) {
     int64_t q = (&M == &Xt) ? tune.xt_q : (&M == &Xth) ? tune.xth_q : tune.x_q;
     if (&M == &Xth) {
       if (q <= 0) q = -(int64_t)(16 / tune.tile_wgs_per_cu * ng) * std::max<int64_t>(1, -q);  // equal split: (-xth_q) segments per lane group and tile
@@ -652,12 +687,15 @@ class Engine : public ImplBase {
     }
     const int xcd_group = (&M == &Xt && tune.xcd_affinity && Xt.pieces.block.size() == Xt.pieces.row.size() &&
                            !Xt.pieces.row.empty()) ? 4 * ng : 0;
-    MNMF_TRY(ensure_segments(M, q, xcd_group));
-    if (M.n_carry > 0) E_HIP(M.carry.ensure((size_t)M.n_carry * ld * sizeof(T)));
-    if (M.n_empty > 0) {
-      zero_rows_kernel<T><<<(unsigned)cdiv(M.n_empty * ld, 256), 256, 0, st()>>>(M.empty_rows.template as<int32_t>(), M.n_empty,
-                                                                                ld, out);
-      E_LAUNCH();
+    if (part != 2) {
+      MNMF_TRY(ensure_segments(M, q, xcd_group));
+      if (M.n_carry > 0) E_HIP(M.carry.ensure((size_t)M.n_carry * ld * sizeof(T)));
+      if (M.n_empty > 0) {
+        zero_rows_kernel<T><<<(unsigned)cdiv(M.n_empty * ld, 256), 256, 0, st()>>>(M.empty_rows.template as<int32_t>(), M.n_empty,
+                                                                                  ld, out);
+        E_LAUNCH();
+      }
+      if (part == 1) return 0;
     }
     // X direction: stage the most frequent rows of the (renumbered) factor in LDS
     int hot = 0;
