@@ -81,3 +81,23 @@ def test_run_nmf_with_device_init_converges_like_host_init():
     eb = np.linalg.norm(X.toarray() - b["W"] @ b["H"])
     assert abs(ea - eb) <= 1e-3 * eb
     assert rel(a["W"], b["W"]) <= 1e-3 and rel(a["H"], b["H"]) <= 1e-3
+
+
+def test_matrix_stays_resident_across_topic_counts():
+    """A topic-count sweep on one matrix object uploads and preprocesses it once (SURVEY.md 8(f) row 2);
+    changing the content in place invalidates the residency."""
+    import manta_amd
+
+    X = zipf_matrix(3000, 4000, 3).tocsr()
+    st = {}
+    a = manta_amd.run_nmf(5, X, norm_thresh=0.005, init="device", dtype="fp32", stats_out=st)
+    first = st["matrix_resident"]
+    b = manta_amd.run_nmf(7, X, norm_thresh=0.005, init="device", dtype="fp32", stats_out=st)
+    assert st["matrix_resident"] and a["W"].shape[1] == 5 and b["W"].shape[1] == 7
+    a2 = manta_amd.run_nmf(5, X, norm_thresh=0.005, init="device", dtype="fp32", stats_out=st)
+    assert st["matrix_resident"] and np.array_equal(a["W"], a2["W"]) and np.array_equal(a["H"], a2["H"])
+    X.data *= 2.0
+    c = manta_amd.run_nmf(5, X, norm_thresh=0.005, init="device", dtype="fp32", stats_out=st)
+    assert not st["matrix_resident"] and not first
+    # the new content was used: the reconstruction doubled (the absolute stopping threshold moves the last iteration)
+    assert rel(c["W"] @ c["H"], 2.0 * (a["W"] @ a["H"])) <= 0.05
