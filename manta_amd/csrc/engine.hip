@@ -84,7 +84,8 @@ struct Tune {
   int tile_min_rows = 448;            // tile stream only if a tile holds at least this many documents ...
   int tile_min_tiles_per_cu = 4;      // ... and there are this many tiles per CU
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
-  int tile_threads = 1024;            // threads of the tile kernel's workgroup (one per CU)
+  int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
+                                      // stream (half of a CU's registers stay free for it), 1024 when it runs alone
   int tile_wgs_per_cu = 1;            // workgroups per CU in the tile kernel (1, 2 or 4)
   int64_t xth_q = 96;                 // X^T tile stream: > 0 target nnz per segment; <= 0: equal split, -xth_q segments per lane group
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
@@ -108,7 +109,8 @@ struct Tune {
     tile_min_tiles_per_cu = (int)geti("MNMF_TILE_MIN_TILES_PER_CU", tile_min_tiles_per_cu);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
-    if (tile_threads != 256 && tile_threads != 512) tile_threads = 1024;
+    if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
+    tile_threads = std::max(256, std::min(1024, tile_threads / 64 * 64));
     tile_wgs_per_cu = (int)geti("MNMF_TILE_WGS", tile_wgs_per_cu);
     if (tile_wgs_per_cu != 2 && tile_wgs_per_cu != 4) tile_wgs_per_cu = 1;
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
@@ -661,14 +663,16 @@ class Engine : public ImplBase {
       }
       MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 1));   // segments + zero rows only
       MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
+      // The tile kernel's workgroups need most of a CU (LDS, registers): they are launched first, on the caller's
+      // stream, so they are resident before the blocked stream's small workgroups fill what is left.
       E_HIP(hipEventRecord(ev_fork, ctx->stream));
       E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+      MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       st_override = side_stream;
-      const int r = spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2);
+      const int r = spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2);
       st_override = nullptr;
       MNMF_TRY(r);
       E_HIP(hipEventRecord(ev_join, side_stream));
-      MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       E_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
       return 0;
     }
