@@ -81,7 +81,7 @@ struct Tune {
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
   int xt_hot_words = 512;             // X^T: this many of the most frequent words go through LDS tiles of W
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
-  int tile_min_rows = 448;            // tile stream only if a tile holds at least this many documents ...
+  int tile_min_rows = 256;            // tile stream only if a tile holds at least this many documents ...
   int tile_min_tiles_per_cu = 4;      // ... and there are this many tiles per CU
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
@@ -644,8 +644,9 @@ class Engine : public ImplBase {
       if (vmap() && tune.xt_hot_words > 0 && nnz >= tune.hot_min_nnz) {
         tile_rows = (int)std::min<int64_t>(tune.tile_lds_bytes / tune.tile_wgs_per_cu / ((int64_t)lds_ld * (int64_t)sizeof(T)), 1 << 15);
         n_hot = (int)std::min<int64_t>(tune.xt_hot_words, V / 2);
-        // worth it only with long pieces (>= ~450 documents per tile: fewer carries than gathers saved; measured
-        // C2 +6 %, C4 +8 %, but C3 with 344-document tiles -4 %) and enough tiles to balance the CUs
+        // worth it only with long pieces (enough documents per tile: fewer carries than gathers saved; measured
+        // beside the blocked stream C2 +10 %, C4 +8 %, C3 with 344-document tiles +6 %) and enough tiles to
+        // balance the CUs
         const int64_t min_rows = tune.tile_min_rows, min_tiles = (int64_t)tune.tile_min_tiles_per_cu * n_cus;
         if (tile_rows < min_rows || n_hot < 8 || cdiv(m, tile_rows) < std::max<int64_t>(min_tiles, 4)) n_hot = 0;
       }
