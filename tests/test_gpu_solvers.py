@@ -193,3 +193,26 @@ def test_determinism(engines):
     a = eng.run_nmf(g["Wr0"], g["Hr0"], fixed_iters=10)
     b = eng.run_nmf(g["Wr0"], g["Hr0"], fixed_iters=10)
     assert np.array_equal(host(a[0]), host(b[0])) and np.array_equal(host(a[1]), host(b[1]))
+
+
+@pytest.mark.parametrize("m,V,k", [(3, 5, 2), (40, 17, 1), (900, 700, 300), (65, 33, 33)])
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_extreme_shapes_against_oracle(engines, dtype, m, V, k):
+    """Tiny matrices, k = 1, k beyond the matrix-core kernels (k > 256) and k just past a tile boundary."""
+    import scipy.sparse as sp
+
+    if dtype == "fp64" and k > 256:
+        pytest.skip("k > 256 unsupported in fp64")
+    rng = np.random.RandomState(m * 31 + k)
+    X = sp.random(m, V, density=min(1.0, 6.0 / V + 0.05), format="csr", random_state=rng, data_rvs=lambda n: rng.rand(n) + 0.1)
+    X.sort_indices()
+    W0, H0 = rng.rand(m, k) + 0.05, rng.rand(k, V) + 0.05
+    want = oc.basic_nmf(X, W0.copy(), H0.copy(), zero_threshold=1e-5, n_iter=7)
+    eng = engines[dtype]
+    eng.set_matrix(X)
+    W, H, st = eng.run_nmf(W0, H0, fixed_iters=7, zero_threshold=1e-5)
+    assert st.iters == 7
+    check_factors({"W": W, "H": H}, want, dtype, zero_exact=False)
+    want = oc.projective_nmf(X, W0.copy(), n_iter=4)
+    W, H, st = eng.run_pnmf(W0, fixed_iters=4)
+    check_factors({"W": W, "H": H}, want, dtype, zero_exact=False)
