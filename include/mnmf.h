@@ -124,6 +124,12 @@ int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* n
  * Frobenius norm (norm_kind 1, nmtf.py:179) for rows x k matrices. */
 int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind,
                    double* out);
+/* The n largest entries of every row (by_column 0) or every column (by_column 1) of the device matrix A (rows x cols,
+ * row-major, the context's dtype), in descending order; on equal values the larger index first.  This is the ranking
+ * rule of topic_extractor.py:294-300 (`np.flip(np.argsort(H[i, :]))`, `W[:, i]`) evaluated where the factors live.
+ * idx_out: groups x n int32 (device; -1 past the end), val_out: groups x n (device). */
+int mnmf_topk(mnmf_ctx* ctx, int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx_out,
+              void* val_out);
 /* Asynchronous device-to-device copy on the context's stream.  No counterpart in the reference;
  * lets a Python all-reduce hook stage an exchange buffer it only knows by address. */
 int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes);

@@ -17,6 +17,7 @@
 #include "gram_mfma.hpp"
 #include "sparse_prep.hpp"
 #include "spmm.hpp"
+#include "topk.hpp"
 
 using namespace mnmf;
 
@@ -33,6 +34,7 @@ struct ImplBase {
                        double eps, int sqrt_mode, void* out) = 0;
   virtual int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) = 0;
   virtual int hook_changed() = 0;
+  virtual int k_topk(int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx, void* val) = 0;
 };
 
 struct mnmf_ctx {
@@ -1462,6 +1464,16 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  int k_topk(int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx, void* val) override {
+    if (rows <= 0 || cols <= 0 || n <= 0 || n > 1024 || !A || !idx || !val) return fail(MNMF_EINVAL, "topk: bad arguments");
+    if ((by_column ? rows : cols) >= ((int64_t)1 << 31)) return fail(MNMF_EINVAL, "topk: more than 2^31 candidates per topic");
+    E_HIP(hipSetDevice(ctx->device));
+    topk_kernel<T><<<(unsigned)(by_column ? cols : rows), 256, 0, st()>>>((const T*)A, rows, cols, by_column, n, idx, (T*)val);
+    E_LAUNCH();
+    E_HIP(hipStreamSynchronize(st()));
+    return 0;
+  }
+
   int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) override {
     if (k <= 0 || rows < 0 || !out) return fail(MNMF_EINVAL, "diff_norm: bad arguments");
     E_HIP(hipSetDevice(ctx->device));
@@ -1550,6 +1562,12 @@ int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* n
 int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind, double* out) {
   if (!ctx || !A || !B) return MNMF_EINVAL;
   return ctx->impl->k_diff_norm(rows, k, A, B, norm_kind, out);
+}
+
+int mnmf_topk(mnmf_ctx* ctx, int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx_out,
+              void* val_out) {
+  if (!ctx) return MNMF_EINVAL;
+  return ctx->impl->k_topk(rows, cols, A, by_column, n, idx_out, val_out);
 }
 
 int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes) {

@@ -233,6 +233,29 @@ class Engine:
                                           float(eps), int(bool(sqrt_mode)), out.data_ptr()))
         return out
 
+    def topk(self, A, n, by_column=False):
+        """The ``n`` largest entries of every row (or column) of ``A``, descending, ties: larger index first.
+        Returns (indices int32 [groups, n], values [groups, n]) as device tensors."""
+        A = self._dev(A)
+        groups = A.shape[1] if by_column else A.shape[0]
+        idx = torch.empty((groups, int(n)), dtype=torch.int32, device=self.device)
+        val = torch.empty((groups, int(n)), dtype=self.tdtype, device=self.device)
+        self._check(self._lib.mnmf_topk(self._h, A.shape[0], A.shape[1], A.data_ptr(), 1 if by_column else 0, int(n),
+                                        idx.data_ptr(), val.data_ptr()))
+        return idx, val
+
+    def topic_rankings(self, W, H, S=None, top_n=15):
+        """Ordered word ids and document ids per topic from factors on the device (topic_extractor.py:265-274 for
+        NMTF -- topic t reads the H row ``argmax(S[t, :])``, :7-23 -- and :294-300 otherwise).  Returns two int32
+        device tensors (topics x top_n)."""
+        W, H = self._dev(W), self._dev(H)
+        words, _ = self.topk(H, top_n, by_column=False)
+        docs, _ = self.topk(W, top_n, by_column=True)
+        if S is not None:
+            rows = torch.argmax(self._dev(S), dim=1)
+            words = words[rows]
+        return words, docs
+
     def diff_norm(self, A, B, kind="spectral"):
         A, B = self._dev(A), self._dev(B)
         if A.shape != B.shape:

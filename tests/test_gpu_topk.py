@@ -1,0 +1,64 @@
+"""Device-side topic rankings (mnmf_topk) against the oracle's ranking rule
+(topic_extractor.py:7-23, 265-274, 294-300: ``np.flip(np.argsort(H[i, :]))``, ``W[:, i]``, NMTF's argmax(S) mapping).
+Integer results: identical wherever the scores are distinct; equal scores rank the larger index first (= flipping a
+stable ascending argsort), which numpy's default sort does not promise, so ties are compared against that rule."""
+import numpy as np
+import pytest
+
+from oracle import nmf_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from manta_amd.engine import Engine
+
+    e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
+    yield e
+    for x in e.values():
+        x.close()
+
+
+def stable_rank(x, n):
+    return np.flip(np.argsort(x, kind="stable"))[:n]
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_topk_rows_and_columns(engines, dtype):
+    eng = engines[dtype]
+    rng = np.random.RandomState(3)
+    A = rng.rand(7, 5000).astype(np.float32 if dtype == "fp32" else np.float64)
+    A[2, 100:140] = 0.75                      # a run of equal values
+    A[3, :] = 0.0                             # a whole row of ties (NNDSVD zeros)
+    A[4, 17] = np.nan
+    idx, val = eng.topk(A, 12)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    for r in range(7):
+        row = np.where(np.isnan(A[r]), -np.inf, A[r])
+        want = stable_rank(row, 12)
+        assert np.array_equal(idx[r], want), r
+        assert np.array_equal(val[r], row[want])
+    B = np.ascontiguousarray(A.T)             # the same data ranked by column (W[:, i])
+    idx2, _ = eng.topk(B, 12, by_column=True)
+    assert np.array_equal(idx2.cpu().numpy(), idx)
+    short, sval = eng.topk(A[:, :5], 8)       # fewer candidates than requested: padded with -1
+    assert np.all(short.cpu().numpy()[:, 5:] == -1) and np.all(np.sort(short.cpu().numpy()[0, :5]) == np.arange(5))
+
+
+@pytest.mark.parametrize("method", ["nmf", "nmtf"])
+def test_topic_rankings_match_oracle(engines, golden, method):
+    g = golden(f"converged_D_600x500_k6_{method}")
+    W, H = g["out_W"], g["out_H"]
+    S = g["out_S"] if method == "nmtf" else None
+    words_ref, docs_ref = oc.topic_rankings(H, W, S, top_n=15)
+    words, docs = engines["fp64"].topic_rankings(W, H, S, top_n=15)
+    words, docs = words.cpu().numpy(), docs.cpu().numpy()
+    k = W.shape[1]
+    for t in range(k):
+        row = int(np.argmax(S[t, :])) if S is not None else t
+        for got, ref, scores in ((words[t], words_ref[t], H[row, :]), (docs[t], docs_ref[t], W[:, t])):
+            same = got == ref
+            # any difference must be a tie in the reference's scores (numpy's default argsort is not stable)
+            assert np.all(scores[got[~same]] == scores[ref[~same]])
+            assert np.array_equal(got, stable_rank(scores, 15))
