@@ -84,7 +84,7 @@ struct Tune {
   int xt_hot_words = 512;             // X^T: this many of the most frequent words go through LDS tiles of W
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 256;            // tile stream only if a tile holds at least this many documents ...
-  int tile_min_tiles_per_cu = 4;      // ... and there are this many tiles per CU
+  int tile_min_tiles_pct = 75;        // ... and there are at least this many tiles, in percent of the CU count
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
                                       // stream (half of a CU's registers stay free for it), 1024 when it runs alone
@@ -108,7 +108,7 @@ struct Tune {
     tile_lds_bytes = geti("MNMF_TILE_LDS_BYTES", tile_lds_bytes);
     xth_q = geti("MNMF_XTH_Q", xth_q);
     tile_min_rows = (int)geti("MNMF_TILE_MIN_ROWS", tile_min_rows);
-    tile_min_tiles_per_cu = (int)geti("MNMF_TILE_MIN_TILES_PER_CU", tile_min_tiles_per_cu);
+    tile_min_tiles_pct = (int)geti("MNMF_TILE_MIN_TILES_PCT", tile_min_tiles_pct);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
     if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
@@ -648,8 +648,8 @@ class Engine : public ImplBase {
         n_hot = (int)std::min<int64_t>(tune.xt_hot_words, V / 2);
         // worth it only with long pieces (enough documents per tile: fewer carries than gathers saved; measured
         // beside the blocked stream C2 +10 %, C4 +8 %, C3 with 344-document tiles +6 %) and enough tiles to
-        // balance the CUs
-        const int64_t min_rows = tune.tile_min_rows, min_tiles = (int64_t)tune.tile_min_tiles_per_cu * n_cus;
+        // occupy the CUs (C2 shards of 500k / 250k / 125k documents +13 / +11 / +5 %, 60k documents -4 %)
+        const int64_t min_rows = tune.tile_min_rows, min_tiles = (int64_t)tune.tile_min_tiles_pct * n_cus / 100;
         if (tile_rows < min_rows || n_hot < 8 || cdiv(m, tile_rows) < std::max<int64_t>(min_tiles, 4)) n_hot = 0;
       }
       MNMF_TRY(ensure_xt(bs, n_hot, tile_rows));

@@ -162,13 +162,13 @@ def hot_engines():
     from manta_amd.engine import Engine
 
     old = {k_: os.environ.get(k_) for k_ in ("MNMF_HOT_MIN_NNZ", "MNMF_HOT_LDS_BYTES", "MNMF_TILE_LDS_BYTES", "MNMF_XT_HOT_WORDS",
-                                             "MNMF_TILE_MIN_ROWS", "MNMF_TILE_MIN_TILES_PER_CU")}
+                                             "MNMF_TILE_MIN_ROWS", "MNMF_TILE_MIN_TILES_PCT")}
     os.environ["MNMF_HOT_MIN_NNZ"] = "0"
     os.environ["MNMF_HOT_LDS_BYTES"] = "20000"
     os.environ["MNMF_TILE_LDS_BYTES"] = "40000"
     os.environ["MNMF_XT_HOT_WORDS"] = "40"
     os.environ["MNMF_TILE_MIN_ROWS"] = "64"
-    os.environ["MNMF_TILE_MIN_TILES_PER_CU"] = "0"
+    os.environ["MNMF_TILE_MIN_TILES_PCT"] = "0"
     try:
         e = {"fp32": Engine(dtype="fp32"), "fp64": Engine(dtype="fp64")}
     finally:
