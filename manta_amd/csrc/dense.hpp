@@ -84,7 +84,13 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const T* __restrict__
 // block 256 = 16 elements x 16 chunk lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const T* __restrict__ slab, int64_t n_chunks,
-                                                          int64_t elems, T* __restrict__ out) {
+                                                          int64_t elems, T* __restrict__ out,
+                                                          const T* __restrict__ slab2 = nullptr, T* __restrict__ out2 = nullptr) {
+  // blockIdx.y == 1: the second slab of a fused launch (two Grams from one update kernel)
+  if (blockIdx.y == 1) {
+    slab = slab2;
+    out = out2;
+  }
   __shared__ T part[16][17];
   const int el = threadIdx.x & 15, cl = threadIdx.x >> 4;
   const int64_t e = (int64_t)blockIdx.x * 16 + el;

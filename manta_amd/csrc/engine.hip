@@ -825,11 +825,13 @@ class Engine : public ImplBase {
     float* s_dif = s_new + nb * elems;
     dense_rk_mfma_f32_kernel<NT, MODE, FUSE><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, s_new, s_dif);
     E_LAUNCH();
-    if (FUSE & 1) {
+    if (FUSE == 3) {  // both Grams in one launch
+      slab_reduce_kernel<float><<<dim3((unsigned)cdiv(elems, 16), 2), 256, 0, st()>>>(s_new, nb, elems, gram_new, s_dif, gram_diff);
+      E_LAUNCH();
+    } else if (FUSE & 1) {
       slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(s_new, nb, elems, gram_new);
       E_LAUNCH();
-    }
-    if (FUSE & 2) {
+    } else if (FUSE & 2) {
       slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(s_dif, nb, elems, gram_diff);
       E_LAUNCH();
     }
