@@ -691,6 +691,10 @@ class Engine : public ImplBase {
       if (q <= 0) q = -(int64_t)(16 / tune.tile_wgs_per_cu * ng) * std::max<int64_t>(1, -q);  // equal split: (-xth_q) segments per lane group and tile
     } else {
       while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
+      // the persistent LDS-hot kernel hands segments to n_cus x 16 waves: keep about six rounds of them, or the last
+      // round's idle tail shows (measured on 1/8 and 1/4 shards of C2: X.H^T -13 % / -5 %)
+      if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= tune.hot_min_nnz)
+        while (q > 32 && M.nnz / q < (int64_t)11 * n_cus * 16 * ng / 2) q >>= 1;
     }
     const int xcd_group = (&M == &Xt && tune.xcd_affinity && Xt.pieces.block.size() == Xt.pieces.row.size() &&
                            !Xt.pieces.row.empty()) ? 4 * ng : 0;
