@@ -31,6 +31,8 @@ CONFIGS = {
     "c2": ("nmf", 1_000_000, 100_000, 0.001, 50),
     "c3": ("pnmf", 1_000_000, 100_000, 0.001, 100),
     "c4": ("nmtf", 2_000_000, 200_000, 0.0005, 20),
+    # one rank's share of configs[4] (20M x 500k, k = 200 over 8 GPUs); with --gpus 8 it is sharded again
+    "c5shard": ("nmf", 2_500_000, 500_000, 0.0002, 200),
 }
 HBM_PEAK_GBS = 8000.0
 L1_GATHER_PEAK_GBS = 28000.0   # measured on MI355X with tools/l1_probe.hip (profiles/r01_l1_gather_probe.txt)
@@ -210,7 +212,9 @@ def main():
     dom_ms = phases[dom]
     achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     ld = (k + 3) // 4 * 4 if k <= 32 else (k + 15) // 16 * 16   # the engine's padded row width
-    traffic, traffic_src = pmc_traffic(args.config, args.dtype, 1 if dom == "spmm_xt" else 0) if world == 1 else (None, None)
+    custom = bool(args.m or args.V or args.k or args.density)   # size overrides: the committed counter passes do not apply
+    traffic, traffic_src = pmc_traffic(args.config, args.dtype, 1 if dom == "spmm_xt" else 0) \
+        if world == 1 and not custom else (None, None)
     # secondary bound: every nnz pulls one ld-wide factor row through the vector memory path;
     # tools/l1_probe.hip measured 28 TB/s for that access (16 B per lane, 4 rows per wave load) with every row in L1
     gather_bytes = nnz_loc * ld * sv
@@ -237,7 +241,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "fp32" else "f64", "data": "synthetic",
             "config": {"workload": f"{method} MU, {m} docs x {V} vocab, density {density}, k={k} "
-                                   f"(BASELINE.json configs[{sorted(CONFIGS).index(args.config)}])",
+                                   + ("(custom size)" if custom else "(one eighth of BASELINE.json configs[4])" if args.config == "c5shard"
+                                      else f"(BASELINE.json configs[{sorted(CONFIGS).index(args.config)}])"),
                        "nnz": nnz, "method": method, "parallelism": f"doc-shard x{world}",
                        "convergence_check": "every iteration (as the reference)",
                        "init": "uniform(0, max X), seed 42", "matrix": "Zipf(1.1) TF-IDF, seed 1234+rank"},
