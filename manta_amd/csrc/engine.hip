@@ -810,7 +810,7 @@ class Engine : public ImplBase {
   template <int NT>
   int rk_mfma_nt(int mode, const RkArgs<float>& a) {
     const int64_t n_tiles = cdiv(a.rows, 32);
-    const unsigned grid = (unsigned)cdiv(n_tiles, 4);
+    const dim3 grid((unsigned)cdiv(n_tiles, 4), (unsigned)cdiv(a.ld, 32 * NT));
     if (mode == RK_PROD) dense_rk_mfma_f32_kernel<NT, RK_PROD, 0><<<grid, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
     else if (mode == RK_MU) dense_rk_mfma_f32_kernel<NT, RK_MU, 0><<<grid, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
     else dense_rk_mfma_f32_kernel<NT, RK_MU_SQRT, 0><<<grid, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
@@ -880,11 +880,7 @@ class Engine : public ImplBase {
       case 1: return rk_mfma_nt<1>(mode, a);
       case 2: return rk_mfma_nt<2>(mode, a);
       case 3: return rk_mfma_nt<3>(mode, a);
-      case 4: return rk_mfma_nt<4>(mode, a);
-      case 5: return rk_mfma_nt<5>(mode, a);
-      case 6: return rk_mfma_nt<6>(mode, a);
-      case 7: return rk_mfma_nt<7>(mode, a);
-      default: return rk_mfma_nt<8>(mode, a);
+      default: return rk_mfma_nt<4>(mode, a);   // ld > 128: column groups of 128 (grid.y), two waves per SIMD each
     }
   }
 

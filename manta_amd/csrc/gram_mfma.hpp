@@ -192,7 +192,7 @@ void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restric
   unsigned goff[NT], eoff[NT];  // byte offsets: G operand (row 8*rh, column), epilogue (row 4*rh, column)
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
-    const int col = 32 * q + cl;
+    const int col = 32 * NT * (int)blockIdx.y + 32 * q + cl;   // blockIdx.y: column group of 32*NT columns (ld > 128)
     cok[q] = col < ld;
     goff[q] = cok[q] ? (unsigned)(8 * rh) * rowb + 4u * col : kPoison;
     eoff[q] = cok[q] ? (unsigned)(4 * rh) * rowb + 4u * col : kPoison;
