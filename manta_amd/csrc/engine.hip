@@ -85,6 +85,7 @@ struct Tune {
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 256;            // tile stream only if a tile holds at least this many documents ...
   int tile_min_tiles_pct = 75;        // ... and there are at least this many tiles, in percent of the CU count
+  int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
                                       // stream (half of a CU's registers stay free for it), 1024 when it runs alone
@@ -109,6 +110,7 @@ struct Tune {
     xth_q = geti("MNMF_XTH_Q", xth_q);
     tile_min_rows = (int)geti("MNMF_TILE_MIN_ROWS", tile_min_rows);
     tile_min_tiles_pct = (int)geti("MNMF_TILE_MIN_TILES_PCT", tile_min_tiles_pct);
+    xt_min_piece = (int)geti("MNMF_XT_MIN_PIECE", xt_min_piece);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
     if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
@@ -434,9 +436,11 @@ class Engine : public ImplBase {
     E_HIP(Xt.vals.ensure(std::max<size_t>(n - (size_t)n_hot_nnz, 1) * sizeof(T)));
     E_HIP(Xth.cols.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * 4));
     E_HIP(Xth.vals.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * sizeof(T)));
+    // a word is cut at document-block boundaries only if its pieces stay long enough to pay for their carry slots
+    const int32_t long_df = (int32_t)std::min<int64_t>(std::max<int64_t>(kSubPiece, (int64_t)tune.xt_min_piece * n_blocks), 1 << 30);
     transpose_key_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), rowid.template as<uint32_t>(),
                                                                    df.template as<int32_t>(), nnz, V, bs, n_blocks,
-                                                                   (int32_t)kSubPiece, (uint32_t)n_hot, (uint32_t)tile_rows,
+                                                                   long_df, (uint32_t)n_hot, (uint32_t)tile_rows,
                                                                    hot_span, key.template as<uint32_t>());
     E_LAUNCH();
     {  // stable sort by key: documents stay ascending inside a piece
