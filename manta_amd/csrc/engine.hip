@@ -85,6 +85,8 @@ struct Tune {
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 256;            // tile stream only if a tile holds at least this many documents ...
   int tile_min_tiles_pct = 75;        // ... and there are at least this many tiles, in percent of the CU count
+  int ld_align_small = 0;             // padding of factor rows with k <= 32 (elements); 0 = whole 128-byte lines (32 floats /
+                                      // 16 doubles): C4, k = 20: 80-byte rows -> 128-byte rows, +10 %; C1, k = 10: +17 %
   int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
@@ -110,6 +112,7 @@ struct Tune {
     xth_q = geti("MNMF_XTH_Q", xth_q);
     tile_min_rows = (int)geti("MNMF_TILE_MIN_ROWS", tile_min_rows);
     tile_min_tiles_pct = (int)geti("MNMF_TILE_MIN_TILES_PCT", tile_min_tiles_pct);
+    ld_align_small = (int)geti("MNMF_LD_ALIGN_SMALL", ld_align_small);
     xt_min_piece = (int)geti("MNMF_XT_MIN_PIECE", xt_min_piece);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
@@ -212,10 +215,12 @@ class Engine : public ImplBase {
   hipStream_t side_stream = nullptr, st_override = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t st() const { return st_override ? st_override : ctx->stream; }
-  // leading dimension of every factor matrix: a multiple of 4 elements; rows of more than 32 elements
-  // are padded to whole 64-byte multiples (tune.ld_align elements) so a gathered row starts line-aligned.
+  // leading dimension of every factor matrix: rows of up to 32 elements fill whole 128-byte lines
+  // (tune.ld_align_small), longer rows are padded to whole 64-byte multiples (tune.ld_align elements),
+  // so a gathered row starts line-aligned and never straddles one line more than it has to.
   int ld_of(int k) const {
-    const int a = (k > 32 && tune.ld_align > 4) ? tune.ld_align : 4;
+    const int small = tune.ld_align_small > 0 ? std::max(4, tune.ld_align_small) : (int)(128 / sizeof(T));
+    const int a = (k > 32 && tune.ld_align > 4) ? tune.ld_align : small;
     return (int)round_up(k, a);
   }
 
