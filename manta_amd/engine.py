@@ -128,6 +128,14 @@ class Engine:
         self._check(self._lib.mnmf_set_matrix(self._h, m, V, nnz, rowptr.data_ptr(), colidx.data_ptr(),
                                               vals.data_ptr(), 1))
         self.m, self.V, self.nnz = m, V, nnz
+        self._vals_minmax = (float(vals.min()), float(vals.max())) if nnz else (0.0, 0.0)
+
+    def value_range(self):
+        """(X.min(), X.max()) as scipy defines them for a sparse matrix: implicit zeros count unless X is full."""
+        lo, hi = self._vals_minmax
+        if self.nnz < self.m * self.V:
+            lo, hi = min(lo, 0.0), max(hi, 0.0)
+        return lo, hi
 
     # ------------------------------------------------------------------ multi-GPU hook
     def set_process_group(self, group=None):

@@ -125,3 +125,42 @@ def nndsvd_device(eng, k: int, **kw):
     kw.setdefault("tol", 1e-10 if eng.dtype == "fp64" else 1e-6)   # a float32 operator cannot resolve less
     u, s, v = truncated_svd_device(eng, k, **kw)
     return nndsvd_from_svd(u, s, v)
+
+
+def _nndsvd_dense_device(A, k: int):
+    """NNDSVD of a small dense factor (tall m x c or wide c x n, c = k + 1) on the device: the k leading singular
+    triplets come from a QR of the tall side and an SVD of the c x c triangle, all float64."""
+    tall = A.shape[0] >= A.shape[1]
+    Q, R = torch.linalg.qr(A if tall else A.t().contiguous())
+    Ur, s, Vrt = torch.linalg.svd(R)
+    u_t, v_t = (Q @ Ur)[:, :k], Vrt.t()[:, :k]
+    if tall:
+        return nndsvd_from_svd(u_t, s[:k], v_t.contiguous())
+    return nndsvd_from_svd(v_t.contiguous(), s[:k], u_t)
+
+
+def nmtf_nndsvd_legacy_device(eng, k: int, **kw):
+    """``nmtf_initialization_nndsvd_legacy`` (nmtf/nmtf_init.py:19-41) for the resident matrix: NNDSVD with k + 1
+    components, then NNDSVD of each of its two factors with k components; S0 = sqrt(S_w @ S_h).
+    Returns W0 (m x k), S0 (k x k), H0 (k x V), float64 device tensors."""
+    if k + 1 > min(eng.m, eng.V):
+        raise ValueError("k + 1 must not exceed min(m, V)")
+    wt, ht = nndsvd_device(eng, k + 1, **kw)
+    w, s_w = _nndsvd_dense_device(wt, k)          # (m x k), (k x (k+1))
+    s_h, h = _nndsvd_dense_device(ht, k)          # ((k+1) x k), (k x V)
+    return w, torch.sqrt(s_w @ s_h), h
+
+
+def random_device(eng, k: int, *, seed: int = 0, with_s: bool = False):
+    """Uniform start in [X.min(), X.max()] (``nmf_initialization_random`` nmf_initialization.py:86-104,
+    ``nmtf_initialization_random`` nmtf_init.py) drawn on the device with a seeded generator.  Same distribution as the
+    reference, not the same stream: numpy's global Mersenne twister is not reproduced."""
+    lo, hi = eng.value_range()
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(seed)
+    def draw(r, c):
+        return torch.rand((r, c), generator=g, device=eng.device, dtype=torch.float64) * (hi - lo) + lo
+    W0 = draw(eng.m, k)
+    S0 = draw(k, k) if with_s else None
+    H0 = draw(k, eng.V)
+    return (W0, S0, H0) if with_s else (W0, H0)

@@ -65,7 +65,9 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     Keyword-only extras (not in the reference): ``dtype`` "fp64" (default; env MANTA_AMD_DTYPE) or
     "fp32"; ``device``; ``max_iter`` / ``fixed_iters`` / ``check_every``; explicit ``W0``/``H0``/``S0``;
     ``init="device"`` computes the NNDSVD start on the GPU (``manta_amd.init_device``: block Lanczos over the
-    engine's SpMM kernels instead of ARPACK on the host; agrees with the host path to ~1e-6, not bit for bit);
+    engine's SpMM kernels instead of ARPACK on the host; agrees with the host path to ~1e-6, not bit for bit; for
+    nmtf it is the legacy double NNDSVD, nmtf_init.py:19-41); ``init="device_random"`` draws the uniform start of
+    ``nmf_initialization_random`` on the GPU (same distribution, its own seeded stream);
     ``stats_out`` dict receives iteration count, norms and timings.
     The engine keeps the last matrix resident: a second call with the same matrix object (unchanged content), as in
     a topic-count sweep, skips the upload and the stream preprocessing (``stats_out["matrix_resident"]``).
@@ -73,14 +75,14 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     del console  # progress output is not reproduced
     dtype = dtype or os.environ.get("MANTA_AMD_DTYPE", "fp64")
     device_init = isinstance(init, str)
-    if device_init and init != "device":
-        raise ValueError("init must be a callable (csc, rank) -> (W0, H0) or the string 'device'")
+    if device_init and init not in ("device", "device_random"):
+        raise ValueError("init must be a callable (csc, rank) -> (W0, H0) or one of the strings 'device', 'device_random'")
     have_init = W0 is not None and H0 is not None
     key = _matrix_key(sparse_matrix)
     resident = key is not None and \
         getattr(_ENGINES.get((dtype, device)), "_resident_key", None) == key   # X (and its streams) already on the GPU
     need_host_matrix = (not resident) or num_of_topics == -1 or (not device_init and not have_init) or \
-        (nmf_method == "nmtf" and (S0 is None or not have_init))
+        (nmf_method == "nmtf" and not device_init and (S0 is None or not have_init))
     csc = sparse_matrix.tocsc() if need_host_matrix else None             # :168
     topic_count = num_of_topics
     if topic_count == -1:
@@ -97,12 +99,15 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
         eng._resident_key = None
         eng.set_matrix(csr)
         eng._resident_key = key
-    if device_init and not have_init:
-        if nmf_method == "nmtf":
-            w = h = None                                                   # discarded by the reference anyway (nmtf.py:224)
+    s_dev = None
+    if device_init and not (have_init and (nmf_method != "nmtf" or S0 is not None)):
+        from . import init_device as idv                                   # starts computed on the matrix already resident
+        if init == "device_random":
+            w, s_dev, h = idv.random_device(eng, topic_count, with_s=True)
+        elif nmf_method == "nmtf":
+            w, s_dev, h = idv.nmtf_nndsvd_legacy_device(eng, topic_count)  # nmtf.py:224
         else:
-            from .init_device import nndsvd_device                         # NNDSVD on the matrix already resident
-            w, h = nndsvd_device(eng, topic_count)
+            w, h = idv.nndsvd_device(eng, topic_count)
     extra = dict(check_every=check_every)
     if max_iter is not None:
         extra["max_iter"] = max_iter
@@ -115,7 +120,9 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
         W, H, st = eng.run_nmf(w, h, norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)  # :122
         out = {"W": W, "H": H}
     else:
-        if S0 is None or W0 is None or H0 is None:
+        if s_dev is not None:
+            s = s_dev
+        elif S0 is None or W0 is None or H0 is None:
             w, s, h = nmtf_initialization_nndsvd_legacy(csr, topic_count)  # nmtf.py:224
         else:
             s = S0

@@ -101,3 +101,54 @@ def test_matrix_stays_resident_across_topic_counts():
     assert not st["matrix_resident"] and not first
     # the new content was used: the reconstruction doubled (the absolute stopping threshold moves the last iteration)
     assert rel(c["W"] @ c["H"], 2.0 * (a["W"] @ a["H"])) <= 0.05
+
+
+@pytest.mark.parametrize("name,k", [("fixed_B_1000x1200_k10", 10), ("fixed_C_500x400_k7", 7), ("fixed_A_300x200_k5", 5)])
+def test_nmtf_legacy_init_device_matches_reference_fixture(golden, name, k):
+    """The legacy double NNDSVD (nmtf_init.py:19-41) on the device against W0/S0/H0 that the reference itself produced
+    (tests/golden, keys Wt0/St0/Ht0).  Tolerance 1e-6 relative Frobenius (float64 engine)."""
+    from manta_amd.engine import Engine
+    from manta_amd.init_device import nmtf_nndsvd_legacy_device
+
+    g = golden(name)
+    eng = Engine(dtype="fp64")
+    try:
+        eng.set_matrix(g["X"].tocsr().astype(np.float64))
+        W0, S0, H0 = nmtf_nndsvd_legacy_device(eng, k)
+        assert W0.shape == g["Wt0"].shape and S0.shape == (k, k) and H0.shape == g["Ht0"].shape
+        errs = (rel(host(W0), g["Wt0"]), rel(host(S0), g["St0"]), rel(host(H0), g["Ht0"]))
+        assert max(errs) <= 1e-6, errs
+    finally:
+        eng.close()
+
+
+def test_random_device_init_and_run_nmf_strings():
+    import manta_amd
+    from manta_amd.engine import Engine
+    from manta_amd.init_device import random_device
+
+    X = zipf_matrix(3000, 2500, 3).tocsr()
+    eng = Engine(dtype="fp32")
+    try:
+        eng.set_matrix(X)
+        assert eng.value_range() == (0.0, pytest.approx(float(X.max()), rel=1e-6))   # float32 engine
+        W0, S0, H0 = random_device(eng, 6, seed=5, with_s=True)
+        W0b, H0b = random_device(eng, 6, seed=5)
+        assert W0.shape == (3000, 6) and S0.shape == (6, 6) and H0.shape == (6, 2500)
+        assert (host(W0) == host(W0b)).all()                            # seeded: reproducible
+        for t in (W0, S0, H0):
+            assert float(t.min()) >= 0.0 and float(t.max()) <= X.max() * (1 + 1e-6)
+        assert abs(float(W0.mean()) - X.max() / 2) <= 0.02 * X.max()
+    finally:
+        eng.close()
+    dense = X.toarray()
+    for method in ("nmf", "nmtf"):
+        for init in ("device", "device_random"):
+            st = {}
+            out = manta_amd.run_nmf(5, X, norm_thresh=0.01, nmf_method=method, init=init, dtype="fp64", max_iter=200,
+                                    stats_out=st)
+            approx = out["W"] @ (out["S"] @ out["H"] if method == "nmtf" else out["H"])
+            assert np.isfinite(approx).all() and st["iters"] >= 1
+            assert np.linalg.norm(dense - approx) < np.linalg.norm(dense)
+    with pytest.raises(ValueError):
+        manta_amd.run_nmf(5, X, init="nonsense")

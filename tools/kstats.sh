@@ -5,6 +5,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ks_$T -o k -
 python3 - <<PY
 import csv
 for r in csv.DictReader(open("$R/gpurun_out/ks_$T/k_kernel_stats.csv")):
-    if "mnmf::spmm" in r["Name"] or "dense_rk" in r["Name"]:
+    if "mnmf::" in r["Name"] and float(r["Percentage"]) > 0.3:
         print("$T", r["Name"][11:75].ljust(66), r["Calls"], round(float(r["AverageNs"])/1e3,1))
 PY
