@@ -8,9 +8,14 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmnmf.so")
-SOURCES = ["engine.hip"]
-DEPS = ["engine.hip", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp",
-        os.path.join("..", "..", "include", "mnmf.h")]
+OBJ = os.path.join(CSRC, "_obj")
+# translation unit -> the files it includes
+SOURCES = {
+    "engine.hip": ["ctx.hpp", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp", "topk.hpp"],
+    "tfidf.hip": ["ctx.hpp", "common.hpp"],
+}
+HEADER = os.path.join(HERE, "..", "include", "mnmf.h")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 
 
 def _hipcc() -> str:
@@ -20,17 +25,36 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.exists(os.path.join(CSRC, d)) and os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(src: str):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in SOURCES[src]] + [HEADER]
+
+
+def needs_build() -> bool:
+    return any(_stale(LIB, _deps(src)) for src in SOURCES)
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
+    """Compile each translation unit that is older than its sources (objects under csrc/_obj) and link libmnmf.so."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + SOURCES
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, _deps(src)):
+            cmd = [_hipcc()] + FLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print("[manta_amd] " + " ".join(cmd), flush=True)
+            subprocess.run(cmd, cwd=CSRC, check=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print("[manta_amd] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, cwd=CSRC, check=True)
@@ -38,4 +62,5 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build_lib(force=True)
+    import sys
+    build_lib(force="--force" in sys.argv or not os.path.exists(LIB) or not needs_build())

@@ -37,17 +37,7 @@ struct ImplBase {
   virtual int k_topk(int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx, void* val) = 0;
 };
 
-struct mnmf_ctx {
-  int device = 0;
-  int dtype = MNMF_F32;
-  hipStream_t stream = nullptr;
-  std::string err;
-  mnmf_allreduce_fn ar = nullptr;
-  void* ar_user = nullptr;
-  int n_ranks = 1;
-  ImplBase* impl = nullptr;
-  void fail(int, const std::string& msg) { err = msg; }
-};
+#include "ctx.hpp"
 
 namespace {
 

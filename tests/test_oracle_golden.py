@@ -103,3 +103,41 @@ def test_rankings_rule():
     S = np.array([[0.1, 0.9], [0.8, 0.2]])
     words, _ = oc.topic_rankings(H, W, S=S, top_n=3)
     assert words.tolist() == [[0, 2, 1], [1, 2, 0]]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# TF-IDF builders: the numpy restatement against outputs of the reference's own functions.
+TFIDF_CASES = ["english_default", "english_nopivot_pagerank", "english_slope_long", "english_slope_off",
+               "turkish_default", "turkish_pagerank"]
+
+
+def load_tfidf_case(tag):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"tfidf_{tag}.npz"), allow_pickle=False)
+    docs = [z["tokens"][z["doc_ptr"][i]:z["doc_ptr"][i + 1]].tolist() for i in range(len(z["doc_ptr"]) - 1)]
+    return z, docs
+
+
+@pytest.mark.parametrize("tag", TFIDF_CASES)
+def test_tfidf_oracle_reproduces_reference_bit_for_bit(tag):
+    from oracle import tfidf_oracle as to
+
+    z, docs = load_tfidf_case(tag)
+    V = int(z["V"])
+    w = z["pagerank"] if "pagerank" in z.files else None
+    if str(z["kind"]) == "english":
+        X = to.tf_idf_english(int(z["N"]), V, docs, use_pivoted_norm=bool(z["use_pivoted_norm"]), slope=float(z["slope"]),
+                              pagerank_weights=w)
+    else:
+        X = to.tf_idf_turkish(docs, V, pagerank_weights=w)
+    assert np.array_equal(X.indptr, z["out_indptr"]) and np.array_equal(X.indices, z["out_indices"])
+    assert np.array_equal(X.data, z["out_data"])                     # bit-exact float64
+
+
+def test_tfidf_oracle_reduceat_errors():
+    from oracle import tfidf_oracle as to
+
+    with pytest.raises(IndexError):                                   # unused last vocabulary id
+        to.tf_idf_english(3, 5, [[0, 1], [2], [3]])
+    with pytest.raises(IndexError):                                   # empty last document
+        to.tf_idf_english(3, 4, [[0, 1], [2, 3], []])
