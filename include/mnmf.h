@@ -133,16 +133,18 @@ int mnmf_topk(mnmf_ctx* ctx, int64_t rows, int64_t cols, const void* A, int by_c
 /* -- TF-IDF construction (the producer of X) --------------------------- */
 /* Term-count matrix of a tokenised corpus, replacing the Counter / lil_matrix loop of
  * tfidf_english_calculator.py:80-87 and tfidf_turkish_calculator.py:37-45.  doc_ptr: int64[m+1] (device), document d
- * owns tokens[doc_ptr[d] .. doc_ptr[d+1]) (int32 vocabulary ids, device).  Pass 1 writes row_nnz[d] = number of
- * distinct tokens of document d; the caller turns it into rowptr (exclusive prefix sum, rowptr[m] = nnz) and pass 2
- * writes each row's distinct ids in ascending order (the canonical CSR of `matris.tocsr()`), their counts, and
- * df[V] = number of documents containing each word (`np.add.reduceat` over the binary CSC copy, :90-92 / :47-49,
- * without its quirk for empty columns, which the Python side reproduces).  MNMF_EINVAL: a token outside [0, V) or a
- * document of more than 8192 tokens (mnmf_last_error says which).  Both calls drain the stream. */
+ * owns tokens[doc_ptr[d] .. doc_ptr[d+1]) (int32 vocabulary ids, device).  Pass 1 sorts and run-length encodes every
+ * document: row_nnz[d] = number of distinct tokens, and the distinct ids (ascending) with their counts are left in the
+ * caller's workspace ws_cols / ws_counts (int32[n_tokens] each, device) at the document's own token offset.  The caller
+ * turns row_nnz into rowptr (exclusive prefix sum, rowptr[m] = nnz) and pass 2 moves each row to its CSR position (the
+ * canonical CSR of `matris.tocsr()`) and writes df[V] = number of documents containing each word (`np.add.reduceat`
+ * over the binary CSC copy, :90-92 / :47-49, without its quirk for empty columns, which the Python side reproduces).
+ * MNMF_EINVAL: a token outside [0, V) or a document of more than 8192 tokens (mnmf_last_error says which).
+ * Both calls drain the stream. */
 int mnmf_tfidf_count_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int32_t* tokens,
-                           int64_t* row_nnz);
-int mnmf_tfidf_fill_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int32_t* tokens,
-                          const int64_t* rowptr, int64_t nnz, int32_t* colidx, int32_t* counts, int32_t* df);
+                           int64_t* row_nnz, int32_t* ws_cols, int32_t* ws_counts);
+int mnmf_tfidf_fill_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int64_t* rowptr, int64_t nnz,
+                          const int32_t* ws_cols, const int32_t* ws_counts, int32_t* colidx, int32_t* counts, int32_t* df);
 /* vals[p] = idf[colidx[p]] / pivot[row] * weight[row] in IEEE double, one rounding per operation: the entry values of
  * `tf_l(binary).multiply(idf)` followed by the pivoted normalisation and the PageRank weighting
  * (tfidf_english_calculator.py:98-127, tfidf_turkish_calculator.py:55-77).  pivot / weight may be NULL (step absent).

@@ -11,8 +11,8 @@ LIB = os.path.join(HERE, "libmnmf.so")
 OBJ = os.path.join(CSRC, "_obj")
 # translation unit -> the files it includes
 SOURCES = {
-    "engine.hip": ["ctx.hpp", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp", "topk.hpp"],
-    "tfidf.hip": ["ctx.hpp", "common.hpp"],
+    "engine.hip": ["ctx.hpp", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp", "topk.hpp", "histogram.hpp"],
+    "tfidf.hip": ["ctx.hpp", "common.hpp", "histogram.hpp"],
 }
 HEADER = os.path.join(HERE, "..", "include", "mnmf.h")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]

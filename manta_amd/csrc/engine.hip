@@ -15,6 +15,7 @@
 #include "dense.hpp"
 #include "eig.hpp"
 #include "gram_mfma.hpp"
+#include "histogram.hpp"
 #include "sparse_prep.hpp"
 #include "spmm.hpp"
 #include "topk.hpp"
@@ -309,14 +310,10 @@ class Engine : public ImplBase {
 
   // df[c] = number of nnz in column c of X (end flags must be clear)
   int column_histogram(int32_t* df) {
-    const int copies = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)64 << 20) / std::max<int64_t>(V * 4, 1)));
+    const int copies = hist_copies(V);
     DevBuf parts;
     E_HIP(parts.ensure((size_t)copies * V * 4));
-    E_HIP(hipMemsetAsync(parts.p, 0, (size_t)copies * V * 4, st()));
-    col_histogram_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, parts.template as<int32_t>(), V, copies);
-    E_LAUNCH();
-    col_histogram_sum_kernel<<<(unsigned)cdiv(V, 256), 256, 0, st()>>>(parts.template as<int32_t>(), V, copies, df);
-    E_LAUNCH();
+    E_HIP(launch_histogram(X.cols.template as<uint32_t>(), nnz, V, ~kEndFlag, parts.template as<int32_t>(), copies, df, st()));
     E_HIP(hipStreamSynchronize(st()));  // parts is freed at scope exit
     return 0;
   }

@@ -243,23 +243,6 @@ __global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int64_t row
   iota[p] = (uint32_t)p;
 }
 
-// Document frequencies.  A frequent word receives a large share of all increments; to keep the atomics from
-// serialising on its counter the blocks spread over `copies` private histograms (block b uses copy b % copies),
-// which col_histogram_sum_kernel adds up.  Integer counts: the result does not depend on the order.
-__global__ void col_histogram_kernel(const uint32_t* __restrict__ cols, int64_t nnz, int32_t* __restrict__ df,
-                                     int64_t V, int copies) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < nnz) atomicAdd(&df[(int64_t)(blockIdx.x % copies) * V + cols[p]], 1);
-}
-
-__global__ void col_histogram_sum_kernel(const int32_t* __restrict__ parts, int64_t V, int copies, int32_t* __restrict__ df) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= V) return;
-  int32_t s = 0;
-  for (int k = 0; k < copies; ++k) s += parts[(int64_t)k * V + c];
-  df[c] = s;
-}
-
 // Sort key of nnz p for the transposed streams.  Words below n_hot (the most frequent ones after the engine's
 // renumbering) go to the TILE stream: key = tile * n_hot + word with tile = document / tile_rows, all below hot_span.
 // The others: hot_span + (document block, word); vocabulary rows with at most `long_df` nnz are not blocked

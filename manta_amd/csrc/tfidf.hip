@@ -12,6 +12,7 @@
 
 #include "common.hpp"
 #include "ctx.hpp"
+#include "histogram.hpp"
 
 using namespace mnmf;
 
@@ -49,15 +50,18 @@ __device__ inline int block_excl_scan(int c, int* tmp, int& total) {
   }
 }
 
-// One workgroup per document (grid-stride).  FILL == false: row_nnz[d] = number of distinct tokens.
-// FILL == true: colidx / counts of row d at rowptr[d].  Documents whose length is outside (lo_len, hi_len] are left to
-// the launch of the other size class.  flags: bit 0 = a token outside [0, V), bit 1 = a document longer than kLargeDoc.
-template <int THREADS, int CAP, bool FILL>
+// One workgroup per document (grid-stride): row_nnz[d] = number of distinct tokens; the distinct ids (ascending) and
+// their counts go to the workspace at the document's own token offset (ws_cols / ws_counts [doc_ptr[d] ..]), from where
+// tfidf_compact_kernel moves them to their CSR position once rowptr is known -- the tokens are sorted once.
+// Documents whose length is outside (lo_len, hi_len] are left to
+// the launch of the other size class.  flags: bit 0 = a token outside [0, V), bit 1 = a document longer than kLargeDoc,
+// bit 2 = the small-class launch met a document of the large class (the large-class launch is skipped otherwise).
+template <int THREADS, int CAP>
 __global__ __launch_bounds__(THREADS) void tfidf_doc_terms_kernel(const int64_t* __restrict__ doc_ptr,
                                                                   const int32_t* __restrict__ tokens, int64_t m, int64_t V,
-                                                                  int lo_len, int hi_len, const int64_t* __restrict__ rowptr,
-                                                                  int64_t* __restrict__ row_nnz, int32_t* __restrict__ colidx,
-                                                                  int32_t* __restrict__ counts, int* __restrict__ flags) {
+                                                                  int lo_len, int hi_len, int64_t* __restrict__ row_nnz,
+                                                                  int32_t* __restrict__ ws_cols, int32_t* __restrict__ ws_counts,
+                                                                  int* __restrict__ flags) {
   __shared__ uint32_t s[CAP];
   __shared__ int tmp[THREADS / 64 + 1];
   const int tid = threadIdx.x;
@@ -65,14 +69,18 @@ __global__ __launch_bounds__(THREADS) void tfidf_doc_terms_kernel(const int64_t*
     const int64_t base = doc_ptr[d];
     const int64_t len64 = doc_ptr[d + 1] - base;
     if (len64 > kLargeDoc) {
-      if (!FILL && tid == 0 && hi_len == kLargeDoc) {
+      if (tid == 0 && hi_len == kSmallDoc) {
         atomicOr(flags, 2);
         row_nnz[d] = 0;
       }
       continue;
     }
     const int len = (int)len64;
-    if (len <= lo_len || len > hi_len) continue;  // workgroup-uniform
+    if (len > hi_len) {                           // left to the launch of the larger size class
+      if (tid == 0) atomicOr(flags, 4);
+      continue;
+    }
+    if (len <= lo_len) continue;                  // workgroup-uniform
     int n = 2;
     while (n < len) n <<= 1;
     __syncthreads();  // the previous document's readers are done with s
@@ -111,20 +119,33 @@ __global__ __launch_bounds__(THREADS) void tfidf_doc_terms_kernel(const int64_t*
     for (int i = p0; i < p1; ++i) c += (i == 0 || s[i] != s[i - 1]);
     int total;
     int r = block_excl_scan<THREADS>(c, tmp, total);
-    if constexpr (!FILL) {
-      if (tid == 0) row_nnz[d] = total;
-    } else {
-      const int64_t out = rowptr[d];
-      for (int i = p0; i < p1; ++i) {
-        if (i == 0 || s[i] != s[i - 1]) {
-          const uint32_t v = s[i];
-          int e = i + 1;
-          while (e < len && s[e] == v) ++e;  // run end (may reach into the next thread's positions)
-          colidx[out + r] = (int32_t)v;
-          counts[out + r] = e - i;
-          ++r;
-        }
+    if (tid == 0) row_nnz[d] = total;
+    for (int i = p0; i < p1; ++i) {
+      if (i == 0 || s[i] != s[i - 1]) {
+        const uint32_t v = s[i];
+        int e = i + 1;
+        while (e < len && s[e] == v) ++e;  // run end (may reach into the next thread's positions)
+        ws_cols[base + r] = (int32_t)v;
+        ws_counts[base + r] = e - i;
+        ++r;
       }
+    }
+  }
+}
+
+// Row d of the workspace (at doc_ptr[d], rowptr[d+1] - rowptr[d] entries) to its CSR position: 16 lanes per row.
+__global__ void tfidf_compact_kernel(int64_t m, const int64_t* __restrict__ doc_ptr, const int64_t* __restrict__ rowptr,
+                                     const int32_t* __restrict__ ws_cols, const int32_t* __restrict__ ws_counts,
+                                     int32_t* __restrict__ colidx, int32_t* __restrict__ counts) {
+  const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t row = g; row < m; row += stride) {
+    const int64_t src = doc_ptr[row], dst = rowptr[row];
+    const int64_t n = rowptr[row + 1] - dst;
+    for (int64_t j = l; j < n; j += 16) {
+      colidx[dst + j] = ws_cols[src + j];
+      counts[dst + j] = ws_counts[src + j];
     }
   }
 }
@@ -150,22 +171,6 @@ __global__ void tfidf_scale_kernel(int64_t m, const int64_t* __restrict__ rowptr
   }
 }
 
-// Document frequencies: blocks spread over `copies` private histograms so a frequent word's counter does not
-// serialise the atomics; integer counts, so the result does not depend on the order.
-__global__ void tfidf_df_kernel(const int32_t* __restrict__ cols, int64_t nnz, int32_t* __restrict__ parts, int64_t V,
-                                int copies) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < nnz) atomicAdd(&parts[(int64_t)(blockIdx.x % copies) * V + cols[p]], 1);
-}
-
-__global__ void tfidf_df_sum_kernel(const int32_t* __restrict__ parts, int64_t V, int copies, int32_t* __restrict__ df) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= V) return;
-  int32_t t = 0;
-  for (int k = 0; k < copies; ++k) t += parts[(int64_t)k * V + c];
-  df[c] = t;
-}
-
 int check_launch(mnmf_ctx* ctx, const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -175,16 +180,22 @@ int check_launch(mnmf_ctx* ctx, const char* what) {
   return 0;
 }
 
-template <bool FILL>
-int launch_doc_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int32_t* tokens,
-                     const int64_t* rowptr, int64_t* row_nnz, int32_t* colidx, int32_t* counts, int* flags) {
+int launch_doc_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int32_t* tokens, int64_t* row_nnz,
+                     int32_t* ws_cols, int32_t* ws_counts, int* flags) {
   const unsigned grid_small = (unsigned)std::min<int64_t>(m, 256 * 64);
   const unsigned grid_large = (unsigned)std::min<int64_t>(m, 256 * 8);
-  tfidf_doc_terms_kernel<64, kSmallDoc, FILL><<<grid_small, 64, 0, ctx->stream>>>(doc_ptr, tokens, m, V, -1, kSmallDoc, rowptr,
-                                                                                 row_nnz, colidx, counts, flags);
+  tfidf_doc_terms_kernel<64, kSmallDoc><<<grid_small, 64, 0, ctx->stream>>>(doc_ptr, tokens, m, V, -1, kSmallDoc, row_nnz, ws_cols,
+                                                                           ws_counts, flags);
   MNMF_TRY(check_launch(ctx, "tfidf_doc_terms_kernel (small)"));
-  tfidf_doc_terms_kernel<256, kLargeDoc, FILL><<<grid_large, 256, 0, ctx->stream>>>(doc_ptr, tokens, m, V, kSmallDoc, kLargeDoc,
-                                                                                   rowptr, row_nnz, colidx, counts, flags);
+  int h = 0;  // documents of the large class are rare: look before launching a second scan over all documents
+  if (hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    ctx->fail(MNMF_EHIP, "tfidf_doc_terms_kernel (small) failed");
+    return MNMF_EHIP;
+  }
+  if (!(h & 4)) return 0;
+  tfidf_doc_terms_kernel<256, kLargeDoc><<<grid_large, 256, 0, ctx->stream>>>(doc_ptr, tokens, m, V, kSmallDoc, kLargeDoc, row_nnz,
+                                                                             ws_cols, ws_counts, flags);
   return check_launch(ctx, "tfidf_doc_terms_kernel (large)");
 }
 
@@ -193,7 +204,7 @@ int launch_doc_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr
 extern "C" {
 
 int mnmf_tfidf_count_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int32_t* tokens,
-                           int64_t* row_nnz) {
+                           int64_t* row_nnz, int32_t* ws_cols, int32_t* ws_counts) {
   if (!ctx) return MNMF_EINVAL;
   if (m < 0 || V < 1 || V > INT32_MAX || !doc_ptr || !row_nnz) {
     ctx->fail(MNMF_EINVAL, "mnmf_tfidf_count_terms: bad arguments");
@@ -205,7 +216,7 @@ int mnmf_tfidf_count_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* d
   MNMF_HIP_TRY(ctx, hipMalloc(&flags, sizeof(int)));
   int rc = MNMF_OK, h = 0;
   if (hipMemsetAsync(flags, 0, sizeof(int), ctx->stream) != hipSuccess) rc = MNMF_EHIP;
-  if (rc == 0) rc = launch_doc_terms<false>(ctx, m, V, doc_ptr, tokens, nullptr, row_nnz, nullptr, nullptr, flags);
+  if (rc == 0) rc = launch_doc_terms(ctx, m, V, doc_ptr, tokens, row_nnz, ws_cols, ws_counts, flags);
   if (rc == 0 && (hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                   hipStreamSynchronize(ctx->stream) != hipSuccess)) {
     ctx->fail(MNMF_EHIP, "mnmf_tfidf_count_terms: reading the flags failed");
@@ -224,10 +235,11 @@ int mnmf_tfidf_count_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* d
   return MNMF_OK;
 }
 
-int mnmf_tfidf_fill_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int32_t* tokens,
-                          const int64_t* rowptr, int64_t nnz, int32_t* colidx, int32_t* counts, int32_t* df) {
+int mnmf_tfidf_fill_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* doc_ptr, const int64_t* rowptr, int64_t nnz,
+                          const int32_t* ws_cols, const int32_t* ws_counts, int32_t* colidx, int32_t* counts, int32_t* df) {
   if (!ctx) return MNMF_EINVAL;
-  if (m < 0 || V < 1 || V > INT32_MAX || nnz < 0 || !doc_ptr || !rowptr || !df || (nnz > 0 && (!colidx || !counts))) {
+  if (m < 0 || V < 1 || V > INT32_MAX || nnz < 0 || !doc_ptr || !rowptr || !df ||
+      (nnz > 0 && (!colidx || !counts || !ws_cols || !ws_counts))) {
     ctx->fail(MNMF_EINVAL, "mnmf_tfidf_fill_terms: bad arguments");
     return MNMF_EINVAL;
   }
@@ -236,33 +248,25 @@ int mnmf_tfidf_fill_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* do
     MNMF_HIP_TRY(ctx, hipMemsetAsync(df, 0, (size_t)V * 4, ctx->stream));
     return MNMF_OK;
   }
-  int* flags = nullptr;
-  MNMF_HIP_TRY(ctx, hipMalloc(&flags, sizeof(int)));
-  int rc = MNMF_OK;
-  if (hipMemsetAsync(flags, 0, sizeof(int), ctx->stream) != hipSuccess) rc = MNMF_EHIP;
-  if (rc == 0) rc = launch_doc_terms<true>(ctx, m, V, doc_ptr, tokens, rowptr, nullptr, colidx, counts, flags);
-  // document frequencies: histogram over the distinct (document, word) pairs, private copies against hot counters
-  const int copies = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)64 << 20) / (V * 4)));
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(m * 16, 256), 256 * 32);
+  tfidf_compact_kernel<<<grid, 256, 0, ctx->stream>>>(m, doc_ptr, rowptr, ws_cols, ws_counts, colidx, counts);
+  int rc = check_launch(ctx, "tfidf_compact_kernel");
+  // document frequencies: histogram over the distinct (document, word) pairs (histogram.hpp)
+  const int copies = hist_copies(V);
   int32_t* parts = nullptr;
   if (rc == 0 && hipMalloc(&parts, (size_t)copies * V * 4) != hipSuccess) {
     ctx->fail(MNMF_EHIP, "mnmf_tfidf_fill_terms: out of device memory");
     rc = MNMF_EHIP;
   }
-  if (rc == 0 && hipMemsetAsync(parts, 0, (size_t)copies * V * 4, ctx->stream) != hipSuccess) rc = MNMF_EHIP;
-  if (rc == 0) {
-    tfidf_df_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, ctx->stream>>>(colidx, nnz, parts, V, copies);
-    rc = check_launch(ctx, "tfidf_df_kernel");
-  }
-  if (rc == 0) {
-    tfidf_df_sum_kernel<<<(unsigned)cdiv(V, 256), 256, 0, ctx->stream>>>(parts, V, copies, df);
-    rc = check_launch(ctx, "tfidf_df_sum_kernel");
+  if (rc == 0 && launch_histogram((const uint32_t*)colidx, nnz, V, 0xFFFFFFFFu, parts, copies, df, ctx->stream) != hipSuccess) {
+    ctx->fail(MNMF_EHIP, "mnmf_tfidf_fill_terms: histogram launch failed");
+    rc = MNMF_EHIP;
   }
   if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == 0) {
     ctx->fail(MNMF_EHIP, "mnmf_tfidf_fill_terms: kernel failed");
     rc = MNMF_EHIP;
   }
   if (parts) (void)hipFree(parts);
-  (void)hipFree(flags);
   return rc;
 }
 

@@ -83,7 +83,10 @@ def term_counts_device(tokens, doc_ptr, V: int, eng=None):
         return _term_counts_global_sort(tokens, doc_ptr, V)
     lib, h = eng._lib, eng._h
     row_nnz = torch.zeros(max(m, 1), dtype=torch.int64, device=eng.device)
-    rc = lib.mnmf_tfidf_count_terms(h, m, V, doc_ptr.data_ptr(), tokens.data_ptr(), row_nnz.data_ptr())
+    ws_cols = torch.empty(max(tokens.numel(), 1), dtype=torch.int32, device=eng.device)     # encoded rows at token offsets
+    ws_counts = torch.empty(max(tokens.numel(), 1), dtype=torch.int32, device=eng.device)
+    rc = lib.mnmf_tfidf_count_terms(h, m, V, doc_ptr.data_ptr(), tokens.data_ptr(), row_nnz.data_ptr(),
+                                    ws_cols.data_ptr(), ws_counts.data_ptr())
     if rc != 0:
         msg = lib.mnmf_last_error(h).decode()
         if "token id" in msg:
@@ -96,8 +99,8 @@ def term_counts_device(tokens, doc_ptr, V: int, eng=None):
     colidx = torch.empty(nnz, dtype=torch.int32, device=eng.device)
     counts = torch.empty(nnz, dtype=torch.int32, device=eng.device)
     df = torch.zeros(V, dtype=torch.int32, device=eng.device)
-    eng._check(lib.mnmf_tfidf_fill_terms(h, m, V, doc_ptr.data_ptr(), tokens.data_ptr(), rowptr.data_ptr(), nnz,
-                                         colidx.data_ptr(), counts.data_ptr(), df.data_ptr()))
+    eng._check(lib.mnmf_tfidf_fill_terms(h, m, V, doc_ptr.data_ptr(), rowptr.data_ptr(), nnz, ws_cols.data_ptr(),
+                                         ws_counts.data_ptr(), colidx.data_ptr(), counts.data_ptr(), df.data_ptr()))
     return rowptr, colidx, counts, df
 
 
