@@ -137,13 +137,26 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     return out
 
 
-def install() -> list:
+def install(tfidf: bool = False) -> list:
     """Rebind ``run_nmf`` inside an installed MANTA.  Callers bind the name at import time
     (modeling_pipeline.py:10, optimization_pipeline.py:16), so the attribute is replaced on each
-    importing module.  Returns the module names that were patched."""
+    importing module.  ``tfidf=True`` also rebinds ``tf_idf_english`` / ``tf_idf_turkish`` where they are bound
+    (english_entry.py:10, turkish_entry.py:4).  Returns the module names that were patched."""
     import importlib
 
     patched = []
+    if tfidf:
+        from . import tfidf as _t
+        for name in ("manta._functions.tfidf", "manta._functions", "manta._functions.english.english_entry",
+                     "manta._functions.turkish.turkish_entry"):
+            try:
+                mod = importlib.import_module(name)
+            except Exception:
+                continue
+            for fn in ("tf_idf_english", "tf_idf_turkish"):
+                if hasattr(mod, fn):
+                    setattr(mod, fn, getattr(_t, fn))
+                    patched.append(f"{name}.{fn}")
     for name in ("manta._functions.nmf.nmf_orchestrator", "manta._functions.nmf", "manta._functions",
                  "manta.pipeline.modeling_pipeline", "manta.pipeline.optimization_pipeline"):
         try:

@@ -221,3 +221,25 @@ def test_engine_refuses_to_run_without_gpu():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Engine()
+
+
+def test_tfidf_flatten_documents_and_reduceat_lengths():
+    """Host side of the TF-IDF builder (manta_amd/tfidf.py): ragged token lists -> flat arrays; the np.add.reduceat
+    document lengths of tfidf_english_calculator.py:107 with their quirk for empty documents."""
+    import torch
+    from manta_amd import tfidf
+
+    docs = [[3, 1, 3], [], [0], [], [], [2, 2, 2, 5]]
+    tokens, ptr = tfidf.flatten_documents(docs)
+    assert tokens.dtype == torch.int32 and ptr.dtype == torch.int64
+    assert tokens.tolist() == [3, 1, 3, 0, 2, 2, 2, 5] and ptr.tolist() == [0, 3, 3, 4, 4, 4, 8]
+    # count matrix rows: [1:1, 3:2], [], [0:1], [], [], [2:3, 5:1]
+    rowptr = torch.tensor([0, 2, 2, 3, 3, 3, 5])
+    counts = torch.tensor([1, 2, 1, 3, 1], dtype=torch.int32)
+    lens = tfidf._reduceat_lengths(ptr, rowptr, counts)
+    data = np.array([1, 2, 1, 3, 1])
+    assert lens.tolist() == np.add.reduceat(data, rowptr[:-1].numpy()).tolist() == [3, 1, 1, 3, 3, 4]
+    with pytest.raises(IndexError):                                   # empty last document
+        tfidf._reduceat_lengths(torch.tensor([0, 2, 2]), torch.tensor([0, 1, 1]), torch.tensor([2], dtype=torch.int32))
+    with pytest.raises(IndexError):
+        tfidf.flatten_documents([[2 ** 40]])
