@@ -78,6 +78,7 @@ struct Tune {
   int tile_min_tiles_pct = 75;        // ... and there are at least this many tiles, in percent of the CU count
   int ld_align_small = 0;             // padding of factor rows with k <= 32 (elements); 0 = whole 128-byte lines (32 floats /
                                       // 16 doubles): C4, k = 20: 80-byte rows -> 128-byte rows, +10 %; C1, k = 10: +17 %
+  int pack_exchange = 1;              // sharded runs: all-reduce only the k live columns of ld-padded rows
   int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
@@ -105,6 +106,7 @@ struct Tune {
     tile_min_tiles_pct = (int)geti("MNMF_TILE_MIN_TILES_PCT", tile_min_tiles_pct);
     ld_align_small = (int)geti("MNMF_LD_ALIGN_SMALL", ld_align_small);
     xt_min_piece = (int)geti("MNMF_XT_MIN_PIECE", xt_min_piece);
+    pack_exchange = (int)geti("MNMF_PACK_EXCHANGE", pack_exchange);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
     if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
@@ -197,7 +199,7 @@ class Engine : public ImplBase {
   const int32_t* vmap() const { return (prepared && tune.permute_vocab && nnz > 0) ? d_newid.template as<int32_t>() : nullptr; }
   int n_cus = 256;
   // solver workspaces
-  DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD;
+  DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD, ar_pack;
   double* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
   double phase_ms[PhaseTimer::kMaxPhases] = {0};
@@ -893,6 +895,25 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  // Exchange of a buffer made of rows of ld elements whose columns k..ld-1 are zero on every rank (factor-shaped
+  // partial products and the Gram blocks behind them): only the k live columns go on the wire.  With rows padded to
+  // whole cache lines the padding is 69 % of the message at k = 10 and 37 % at k = 20; the exchange is the one part of
+  // a sharded iteration that nothing can hide.  Below 25 % padding (k = 50: 22 %) the two copy kernels cost about what
+  // the shorter message saves, and the buffer goes out as it is.
+  int allreduce_rows(T* p, int64_t count, int k, int ld) {
+    if (!ctx->ar) return 0;
+    if (!tune.pack_exchange || count % ld != 0 || (ld - k) * 4 < ld) return allreduce(p, count);  // < 25 % padding: as is
+    const int64_t rows = count / ld;
+    E_HIP(ar_pack.ensure((size_t)rows * k * sizeof(T)));
+    T* q = ar_pack.template as<T>();
+    unpad_rows_kernel<T><<<(unsigned)cdiv(rows * k, 256), 256, 0, st()>>>(p, rows, k, ld, T(0), q);
+    E_LAUNCH();
+    MNMF_TRY(allreduce(q, rows * k));
+    pad_rows_kernel<T><<<(unsigned)cdiv(rows * ld, 256), 256, 0, st()>>>(q, rows, k, ld, p);
+    E_LAUNCH();
+    return 0;
+  }
+
   // lambda_max / trace of device Gram(s) -> host.  grams: n matrices of ld x ld, contiguous.
   int fetch_grams(const T* d, int n, int ld, std::vector<double>& out) {
     const size_t cnt = (size_t)n * ld * ld;
@@ -1066,7 +1087,7 @@ class Engine : public ImplBase {
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
       pt.mark(1);
-      MNMF_TRY(allreduce(Nh, (int64_t)V * ld + (int64_t)ld * ld));
+      MNMF_TRY(allreduce_rows(Nh, (int64_t)V * ld + (int64_t)ld * ld, k, ld));
       // h update :41-42, with h_hT of the new h (:44) and, for the norms, D^T D of D = |h - h_old| (:53) in the same pass
       MNMF_TRY(rk_grams(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps, Gh, do_check ? Gd + (size_t)ld * ld : nullptr));
       pt.mark(2);
@@ -1176,7 +1197,7 @@ class Engine : public ImplBase {
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, vtw));                                   // vtw = X.T @ W       :69
       pt.mark(1);
-      MNMF_TRY(allreduce(vtw, (int64_t)V * ld + (int64_t)ld * ld));
+      MNMF_TRY(allreduce_rows(vtw, (int64_t)V * ld + (int64_t)ld * ld, k, ld));
       MNMF_TRY(spmm(X, vtw, ld, pay));                                   // pay = X @ vtw       :72
       pt.mark(4);
       MNMF_TRY(gram(Wc, nullptr, pay, nullptr, m, ld, false, wt_pay));  // wt_pay = W.T @ pay  :75
@@ -1222,7 +1243,7 @@ class Engine : public ImplBase {
       }
     }
     MNMF_TRY(spmm(Xt, Wc, ld, vtw));                                      // h = w.T @ X         :115
-    MNMF_TRY(allreduce(vtw, (int64_t)V * ld));
+    MNMF_TRY(allreduce_rows(vtw, (int64_t)V * ld, k, ld));
     MNMF_TRY(store_W(Wc, k, ld, -1.0, W));
     MNMF_TRY(store_H(vtw, k, ld, -1.0, H));
     E_HIP(hipStreamSynchronize(st()));
@@ -1316,7 +1337,7 @@ class Engine : public ImplBase {
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wn, ld, Pt));                                    // (w1.T @ in_mat)^T
       pt.mark(1);
-      MNMF_TRY(allreduce(Pt, (int64_t)V * ld + (int64_t)gel));
+      MNMF_TRY(allreduce_rows(Pt, (int64_t)V * ld + (int64_t)gel, k, ld));
       MNMF_TRY(gram(Pt, nullptr, Hc, nullptr, V, ld, false, num_s));    // (w1.T X) @ h.T
       MNMF_TRY(kxk(Gw1, Sc, T2, ld, 0, 0));
       MNMF_TRY(kxk(T2, hhT, den_s, ld, 0, 0));                           // (w1T w1) s (h hT)
