@@ -264,6 +264,30 @@ class Engine:
             words = words[rows]
         return words, docs
 
+    def relevance_rankings(self, W, H, S=None, lambda_val=0.6, top_n=15):
+        """LDAvis-style relevance ranking of the coherence step evaluated where the factors live
+        (gensim_coherence.py:40-140): relevance = lambda * log p(word|topic) + (1 - lambda) * log lift, words with topic
+        weight <= 1e-10 excluded.  Returns (word ids int32 [topics, top_n], -1 past the valid ones; relevance float64).
+        The arithmetic is float64 on the device whatever the engine's dtype; ties rank the larger id first."""
+        def f64(a):                                    # not through the engine's dtype: float64 inputs stay float64
+            return (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))).to(self.device, torch.float64)
+        W, H = f64(W), f64(H)
+        topic_weights = W.sum(dim=0)
+        term_frequency = (H * topic_weights[:, None]).sum(dim=0)
+        overall = term_frequency / (term_frequency.sum() + 1e-10)
+        if S is not None:
+            H = H[torch.argmax(f64(S), dim=1)]
+        p = H / (H.sum(dim=1, keepdim=True) + 1e-10)
+        lift = torch.clamp(p / (overall + 1e-10), min=1e-10)
+        rel = lambda_val * torch.log(p + 1e-10) + (1 - lambda_val) * torch.log(lift)
+        masked = torch.where(H > 1e-10, rel, torch.full_like(rel, float("-inf")))
+        eng = self
+        if self.dtype != "fp64":                       # rank in float64: a float32 copy would merge close scores
+            from .nmf import _engine
+            eng = _engine("fp64", self.device)
+        idx, val = eng.topk(masked.contiguous(), top_n)
+        return torch.where(torch.isinf(val), torch.full_like(idx, -1), idx), val
+
     def diff_norm(self, A, B, kind="spectral"):
         A, B = self._dev(A), self._dev(B)
         if A.shape != B.shape:

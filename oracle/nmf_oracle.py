@@ -280,6 +280,33 @@ def topic_rankings(H, W, S=None, top_n=15):
     return np.array(words), np.array(docs)
 
 
+def relevance_rankings(H, W, S=None, lambda_val=0.6, top_n=15):
+    """LDAvis-style relevance ranking used by the coherence step, before any vocabulary string filtering
+    (manta/utils/analysis/gensim_coherence.py:40-103 and :106-140): per topic the word ids in descending relevance
+    (-1 where fewer than top_n words have weight > 1e-10) and the relevance values.
+    PARITY UNPINNED: that module imports gensim, which is absent here, so this restatement could not be run against
+    the reference function; it follows its lines one by one."""
+    H, W = np.asarray(H), np.asarray(W)
+    topic_weights = W.sum(axis=0)                                              # :71
+    term_frequency = np.sum(H * topic_weights.reshape(-1, 1), axis=0)          # :72
+    overall = term_frequency / (term_frequency.sum() + 1e-10)                  # :73
+    k = W.shape[1] if S is not None else H.shape[0]
+    idx = np.full((k, top_n), -1, dtype=np.int64)
+    val = np.full((k, top_n), -np.inf)
+    for t in range(k):
+        row = int(np.argmax(np.asarray(S)[t, :])) if S is not None else t      # :24-37, :82-84
+        v = H[row]
+        p = v / (v.sum() + 1e-10)                                              # :121
+        lift = np.clip(p / (overall + 1e-10), 1e-10, None)                     # :124-125
+        rel = lambda_val * np.log(p + 1e-10) + (1 - lambda_val) * np.log(lift)  # :127-130
+        masked = np.where(v > 1e-10, rel, -np.inf)                             # :134-135
+        top = np.argsort(masked)[::-1][:top_n]                                 # :137
+        ok = masked[top] > -np.inf
+        idx[t, :ok.sum()] = top[ok]
+        val[t, :ok.sum()] = rel[top[ok]]
+    return idx, val
+
+
 # --------------------------------------------------------------------------- fp32 emulation (tolerance calibration / CPU baseline)
 def basic_nmf_f32(X, w, h, n_iter):
     """Loop A carried in float32 (not in the reference; calibrates the GPU fp32 tolerance)."""

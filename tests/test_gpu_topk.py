@@ -62,3 +62,31 @@ def test_topic_rankings_match_oracle(engines, golden, method):
             # any difference must be a tie in the reference's scores (numpy's default argsort is not stable)
             assert np.all(scores[got[~same]] == scores[ref[~same]])
             assert np.array_equal(got, stable_rank(scores, 15))
+
+
+@pytest.mark.parametrize("method", ["nmf", "nmtf"])
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_relevance_rankings_match_oracle(engines, golden, method, dtype):
+    """Relevance re-ranking of the coherence step (gensim_coherence.py:40-140) on the device against the numpy
+    restatement (parity unpinned: gensim is absent, the reference function cannot be run here).  Word ids identical
+    wherever adjacent relevance values differ by more than 1e-9; values within 1e-9."""
+    g = golden(f"converged_D_600x500_k6_{method}")
+    W, H = g["out_W"], g["out_H"]
+    S = g["out_S"] if method == "nmtf" else None
+    for lam in (0.6, 0.0, 1.0):
+        idx_ref, val_ref = oc.relevance_rankings(H, W, S, lambda_val=lam, top_n=20)
+        idx, val = engines[dtype].relevance_rankings(W, H, S, lambda_val=lam, top_n=20)
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        assert idx.shape == idx_ref.shape
+        valid = idx_ref >= 0
+        assert np.array_equal(idx >= 0, valid)
+        assert np.allclose(val[valid], val_ref[valid], rtol=0, atol=1e-9)
+        diff = (idx != idx_ref) & valid
+        for t, j in zip(*np.nonzero(diff)):                      # only near-ties may swap
+            assert abs(val_ref[t, j] - val[t, j]) <= 1e-9
+    # a topic row with fewer valid words than top_n
+    H2 = H.copy()
+    H2[0, 5:] = 0.0
+    idx, val = engines[dtype].relevance_rankings(W, H2, None if S is None else S, top_n=10)
+    idx_ref, _ = oc.relevance_rankings(H2, W, S, top_n=10)
+    assert np.array_equal(idx.cpu().numpy() >= 0, idx_ref >= 0)
