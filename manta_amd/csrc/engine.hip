@@ -1200,8 +1200,10 @@ class Engine : public ImplBase {
       MNMF_TRY(allreduce_rows(vtw, (int64_t)V * ld + (int64_t)ld * ld, k, ld));
       MNMF_TRY(spmm(X, vtw, ld, pay));                                   // pay = X @ vtw       :72
       pt.mark(4);
-      MNMF_TRY(gram(Wc, nullptr, pay, nullptr, m, ld, false, wt_pay));  // wt_pay = W.T @ pay  :75
-      MNMF_TRY(allreduce(wt_pay, (int64_t)ld * ld));
+      // wt_pay = W.T @ pay (:75) = W.T @ X @ vtw = vtw.T @ vtw: the Gram of the (summed) V x k matrix instead of a
+      // product over the m document rows -- symmetric, a tenth of the rows at C3, and in a sharded run every rank
+      // computes it from the exchanged vtw, so the second all-reduce of the iteration is gone.
+      MNMF_TRY(gram(vtw, nullptr, vtw, nullptr, V, ld, false, wt_pay));
       pt.mark(3);
       // payda = W @ wt_pay + pay @ wtw + eps ; w_new = W * sqrt(pay / payda)                  :76-79
       // ... with the next iteration's wtw (:68) and D^T D of D = |w_new - W| (:83) in the same pass

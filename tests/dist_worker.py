@@ -44,7 +44,7 @@ def emulate(method, X, W, H, S, N):
             ex = allreduce(np.concatenate([(X.T @ W).ravel(), (W.T @ W).ravel()]))   # [vtw | wtw]
             vtw, wtw = ex[:V * k].reshape(V, k), ex[V * k:].reshape(k, k)
             pay = X @ vtw
-            wt_pay = allreduce(W.T @ pay)
+            wt_pay = vtw.T @ vtw                 # = W.T @ X @ vtw = W.T @ pay over all ranks: no second exchange
             W = W * np.sqrt(pay / (W @ wt_pay + pay @ wtw + oc.PNMF_EPS))
         W = W.copy()
         W[W < oc.PNMF_ZERO] = 0
