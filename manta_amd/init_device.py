@@ -20,6 +20,46 @@ import math
 import torch
 
 
+def _tsgemm(A, B, splits: int = 64):
+    """A^T @ B for tall A (n x p) and B (n x q), float64.  The library GEMM gives one workgroup per 64 x 64 output tile
+    and lets it walk all n rows alone (2.9 ms for 100k x 230 here); cutting the rows into slabs and summing the slab
+    products (one batched GEMM) spreads the same work over the whole chip."""
+    n = A.shape[0]
+    s = max(1, min(splits, n // 2048))
+    if s == 1:
+        return A.t() @ B
+    n0 = (n // s) * s
+    out = torch.bmm(A[:n0].reshape(s, n0 // s, A.shape[1]).transpose(1, 2), B[:n0].reshape(s, n0 // s, B.shape[1])).sum(0)
+    if n0 < n:
+        out = out + A[n0:].t() @ B[n0:]
+    return out
+
+
+def _orthonormal_columns(Z, drop: bool = True):
+    """Orthonormal basis of the columns of a tall block: CholeskyQR2 (two rounds of Gram -> Cholesky -> Z.L^-T, all
+    GEMM-shaped) when the block is well conditioned, Householder QR with the numerically dependent columns dropped
+    otherwise (``drop=False``: return None instead, the caller keeps every column)."""
+    if Z.shape[1] == 0:
+        return Z
+    W = Z
+    ok = True
+    for _ in range(2):
+        L, bad = torch.linalg.cholesky_ex(_tsgemm(W, W))
+        d = L.diagonal()
+        if int(bad) != 0 or not bool(torch.isfinite(d).all()) or float(d.min()) < 1e-5 * float(d.max()):
+            ok = False
+            break
+        W = W @ torch.linalg.inv(L).t()
+    if ok:
+        return W
+    if not drop:
+        return None
+    Zq, R = torch.linalg.qr(Z)
+    d = R.diagonal().abs()
+    good = d > 1e-12 * max(float(d.max()), 1e-300)
+    return Zq[:, good]
+
+
 def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = None, tol: float = 1e-10,
                          seed: int = 0, max_steps: int = 2000, info: dict | None = None):
     """Leading ``k`` singular triplets (u: m x k, s: k, v: V x k, float64 device tensors, s descending) of the
@@ -44,15 +84,13 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
 
     def orth_against(Z, Q):
         for _ in range(2):
-            Z = Z - Q @ (Q.t() @ Z)
-        Zq, R = torch.linalg.qr(Z)
-        d = R.diagonal().abs()
-        good = d > 1e-12 * max(float(d.max()), 1e-300)
-        return Zq[:, good]
+            Z = Z - Q @ _tsgemm(Q, Z)
+        return _orthonormal_columns(Z)
 
-    Vj, _ = torch.linalg.qr(torch.randn((V, b), generator=g, device=dev, dtype=torch.float64))
+    Vj = _orthonormal_columns(torch.randn((V, b), generator=g, device=dev, dtype=torch.float64))
     Q = torch.empty((V, 0), device=dev, dtype=torch.float64)     # orthonormal basis
     AQ = torch.empty((V, 0), device=dev, dtype=torch.float64)    # X^T.X applied to it
+    T = torch.empty((0, 0), device=dev, dtype=torch.float64)     # Q^T.A.Q, grown by one block row/column per step
     steps, restarts, converged = 0, 0, False
     while True:
         Y = eng.spmm(Vj.to(dt).contiguous())                      # X . Vj           (m x b)
@@ -61,11 +99,17 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
         AQ = torch.cat([AQ, Z], dim=1)
         steps += 1
         dim = Q.shape[1]
-        T = Q.t() @ AQ
+        C = _tsgemm(Q, Z)                                         # new block column of T (A is symmetric: row = C^T)
+        Tn = torch.empty((dim, dim), device=dev, dtype=torch.float64)
+        old = T.shape[0]
+        Tn[:old, :old] = T
+        Tn[:, old:] = C
+        Tn[old:, :old] = C[:old].t()
+        T = Tn
         evals, evecs = torch.linalg.eigh(0.5 * (T + T.t()))
         kk = min(k, dim)
         theta = evals[-kk:].flip(0)
-        S = evecs[:, -kk:].flip(1)
+        S = evecs[:, -kk:].flip(1).contiguous()
         Res = AQ @ S - (Q @ S) * theta
         rn = torch.linalg.norm(Res, dim=0)
         if dim >= k and float(rn.max()) <= tol * float(theta[0]):
@@ -75,10 +119,19 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
             break
         if dim + b > max_dim:                                     # thick restart on the leading Ritz vectors
             p = min(keep, dim)
-            Sp = evecs[:, -p:].flip(1)
+            Sp = evecs[:, -p:].flip(1).contiguous()
             Q, AQ = Q @ Sp, AQ @ Sp
-            Q, Rq = torch.linalg.qr(Q)                            # keep the basis orthonormal to machine precision
-            AQ = AQ @ torch.linalg.inv(Rq)
+            G = _tsgemm(Q, Q)                                     # keep the basis orthonormal to machine precision:
+            L, bad = torch.linalg.cholesky_ex(G)                  # Q <- Q.R^-1, AQ <- AQ.R^-1 with R = L^T
+            if int(bad) == 0:
+                Rinv = torch.linalg.inv(L).t()
+            else:
+                Q, Rq = torch.linalg.qr(Q)
+                Rinv = None
+                AQ = AQ @ torch.linalg.inv(Rq)
+            if Rinv is not None:
+                Q, AQ = Q @ Rinv, AQ @ Rinv
+            T = _tsgemm(Q, AQ)
             restarts += 1
         worst = torch.argsort(rn, descending=True)[:b]
         Vj = orth_against(Res[:, worst], Q)
@@ -89,7 +142,9 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
     if info is not None:
         info.update(steps=steps, restarts=restarts, converged=converged, dim=int(Q.shape[1]),
                     max_residual=float(rn.max() / theta[0]))
-    v, _ = torch.linalg.qr(Q @ S)                                 # polish orthonormality (columns keep their order)
+    v = Q @ S                                                     # polish orthonormality (columns keep their order)
+    vq = _orthonormal_columns(v, drop=False)
+    v = vq if vq is not None else torch.linalg.qr(v)[0]
     u = torch.empty((m, k), device=dev, dtype=torch.float64)
     for c0 in range(0, k, 128):                                   # the engine takes up to 256 (f64) columns per call
         c1 = min(k, c0 + 128)
