@@ -81,19 +81,24 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     key = _matrix_key(sparse_matrix)
     resident = key is not None and \
         getattr(_ENGINES.get((dtype, device)), "_resident_key", None) == key   # X (and its streams) already on the GPU
-    need_host_matrix = (not resident) or num_of_topics == -1 or (not device_init and not have_init) or \
+    host_init = (not device_init and not have_init) or \
         (nmf_method == "nmtf" and not device_init and (S0 is None or not have_init))
-    csc = sparse_matrix.tocsc() if need_host_matrix else None             # :168
+    # the reference converts to CSC first (:168) and to CSR for the solvers (:116); the CSC copy is only made here when
+    # something on the host reads it (a host init): at C2 each scipy conversion of 1e8 nnz costs about a second
+    csc = sparse_matrix.tocsc() if host_init else None
     topic_count = num_of_topics
-    if topic_count == -1:
-        topic_count = find_max_rank(csc)                                   # :105-106
+    if topic_count == -1:                                                  # :105-106 (same value in any format)
+        topic_count = find_max_rank(csc) if csc is not None else \
+            int(sparse_matrix.count_nonzero() / (sparse_matrix.shape[0] + sparse_matrix.shape[1]))
     if have_init:
         w, h = W0, H0
     elif not device_init:
         w, h = init(csc, topic_count)                                      # :109
     if nmf_method not in ("nmf", "pnmf", "nmtf"):
         raise ValueError(f"Unknown NMF method: {nmf_method}. Supported methods are: 'nmf', 'pnmf', 'nmtf'")  # :130
-    csr = csc.tocsr() if csc is not None else None                         # :116
+    csr = None
+    if not resident or host_init:
+        csr = (csc if csc is not None else sparse_matrix).tocsr()          # :116
     eng = _engine(dtype, device)
     if not resident:
         eng._resident_key = None
