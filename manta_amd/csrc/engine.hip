@@ -1189,6 +1189,18 @@ class Engine : public ImplBase {
     PhaseTimer pt(st(), o && o->profile_phases);
     pt.mark(-1);
     std::vector<double> g;
+    // The norm of iteration i is read while iteration i+1's SpMMs are already queued (they only read W_{i+1}); the
+    // reference breaks BEFORE assigning w_new (:101-107), so when iteration i turns out to have converged the flip
+    // is undone -- W_i is still intact, iteration i+1 has not reached its update yet.
+    bool pending = false;
+    auto resolve = [&]() -> int {
+      MNMF_TRY(fetch_end(g));
+      pending = false;
+      w_norm = spectral_from_gram(g.data(), ld);
+      if (!std::isfinite(w_norm)) return fail(MNMF_ENAN, "pnmf: non-finite update norm at iteration " + std::to_string(i));
+      return 0;
+    };
+    MNMF_TRY(pinned((size_t)ld * ld));
     while (i < limit) {                                                  // nmf_projective_basic.py:61
       T* Wc = Wb[cw].template as<T>();
       T* Wn = Wb[1 - cw].template as<T>();
@@ -1205,6 +1217,20 @@ class Engine : public ImplBase {
       // computes it from the exchanged vtw, so the second all-reduce of the iteration is gone.
       MNMF_TRY(gram(vtw, nullptr, vtw, nullptr, V, ld, false, wt_pay));
       pt.mark(3);
+      if (pending) {  // norm of the previous iteration                  :83, :101
+        const int r = resolve();
+        pt.mark(6);
+        if (r != 0) {
+          (void)clock_stop(clk, stats);
+          return r;
+        }
+        if (fixed <= 0 && w_norm < delta) {                              // break BEFORE W = w_new   :101-107
+          converged = 1;
+          cw = 1 - cw;
+          --i;
+          break;
+        }
+      }
       // payda = W @ wt_pay + pay @ wtw + eps ; w_new = W * sqrt(pay / payda)                  :76-79
       // ... with the next iteration's wtw (:68) and D^T D of D = |w_new - W| (:83) in the same pass
       MNMF_TRY(rk_grams(RK_MU_SQRT, Wc, wt_pay, pay, wtw, Wc, pay, Wn, m, ld, eps, wtw, do_check ? Gd : nullptr));
@@ -1212,20 +1238,26 @@ class Engine : public ImplBase {
       pt.mark(5);
       if (do_check) {
         MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
-        MNMF_TRY(fetch_grams(Gd, 1, ld, g));
-        w_norm = spectral_from_gram(g.data(), ld);
+        MNMF_TRY(fetch_begin((size_t)ld * ld));
+        MNMF_TRY(fetch_add(Gd, (size_t)ld * ld));
+        MNMF_TRY(fetch_commit());
+        pending = true;
         pt.mark(6);
-        if (!std::isfinite(w_norm)) {
-          (void)clock_stop(clk, stats);
-          return fail(MNMF_ENAN, "pnmf: non-finite update norm at iteration " + std::to_string(i + 1));
-        }
-        if (fixed <= 0 && w_norm < delta) {                              // break BEFORE W = w_new   :101-107
-          converged = 1;
-          break;
-        }
       }
       cw = 1 - cw;
       ++i;
+    }
+    if (pending) {  // the loop ended on its iteration cap: the last iteration's norm
+      const int r = resolve();
+      if (r != 0) {
+        (void)clock_stop(clk, stats);
+        return r;
+      }
+      if (fixed <= 0 && w_norm < delta) {
+        converged = 1;
+        cw = 1 - cw;
+        --i;
+      }
     }
     MNMF_TRY(clock_stop(clk, stats));
     pt.collect(phase_ms);
@@ -1310,9 +1342,29 @@ class Engine : public ImplBase {
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
     pt.mark(-1);
-    std::vector<double> g, sh;
+    std::vector<double> g;
     const unsigned kb = (unsigned)cdiv((int64_t)gel, 256);
     bool hht_valid = false;  // hhT holds h @ h.T of the current h (left there by the previous h update)
+    // The norms of iteration i are read while iteration i+1 is already queued up to its W update: that work only
+    // writes scratch and the other halves of the ping-pong buffers, so when iteration i turns out to have converged
+    // the factors it produced are still current and the queued work is simply dropped.
+    bool pending = false;
+    auto resolve = [&]() -> int {
+      MNMF_TRY(fetch_end(g));
+      pending = false;
+      w_norm = fro_from_gram(g.data(), ld);
+      h_norm = fro_from_gram(g.data() + gel, ld);
+      double acc = 0;
+      for (size_t e = 0; e < gel; ++e) {
+        const double d = g[2 * gel + e] - g[3 * gel + e];
+        acc += d * d;
+      }
+      s_norm = std::sqrt(acc);
+      if (!std::isfinite(w_norm) || !std::isfinite(h_norm) || !std::isfinite(s_norm))
+        return fail(MNMF_ENAN, "nmtf: non-finite update norm at iteration " + std::to_string(i));
+      return 0;
+    };
+    MNMF_TRY(pinned(4 * gel));
     while (true) {
       T* Wc = Wb[cw].template as<T>();
       T* Wn = Wb[1 - cw].template as<T>();
@@ -1331,6 +1383,18 @@ class Engine : public ImplBase {
       pt.mark(3);
       MNMF_TRY(kxk(Sc, hhT, T1, ld, 0, 0));                              // s (h hT)
       MNMF_TRY(kxk(T1, Sc, Dm, ld, 0, 1));                               // s (h hT) sT
+      if (pending) {  // norms of the previous iteration                 :179-181, :200
+        const int r = resolve();
+        pt.mark(6);
+        if (r != 0) {
+          (void)clock_stop(clk, stats);
+          return r;
+        }
+        if (fixed <= 0 && w_norm < thr && h_norm < thr && s_norm < thr) {
+          converged = 1;
+          break;
+        }
+      }
       const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
       // w update with w1.T @ w1 (:157) and, for the norms, D^T D of D = |w1 - w| (:179) in the same pass
       MNMF_TRY(rk_grams(RK_MU, Wc, Dm, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw1, do_check ? Gd : nullptr));
@@ -1356,21 +1420,12 @@ class Engine : public ImplBase {
       pt.mark(2);
       if (do_check) {                                                     // Frobenius norms   nmtf.py:179-181
         MNMF_TRY(allreduce(Gd, (int64_t)gel));
-        MNMF_TRY(fetch_grams(Gd, 2, ld, g));
-        w_norm = fro_from_gram(g.data(), ld);
-        h_norm = fro_from_gram(g.data() + gel, ld);
-        MNMF_TRY(fetch_grams(Sb[0], 2, ld, sh));
-        double acc = 0;
-        for (size_t e = 0; e < gel; ++e) {
-          const double d = sh[e] - sh[gel + e];
-          acc += d * d;
-        }
-        s_norm = std::sqrt(acc);
+        MNMF_TRY(fetch_begin(4 * gel));
+        MNMF_TRY(fetch_add(Gd, 2 * gel));          // [dW gram | dH gram]
+        MNMF_TRY(fetch_add(Sb[0], 2 * gel));       // both S buffers: ||s1 - s||_F on the host
+        MNMF_TRY(fetch_commit());
+        pending = true;
         pt.mark(6);
-        if (!std::isfinite(w_norm) || !std::isfinite(h_norm) || !std::isfinite(s_norm)) {
-          (void)clock_stop(clk, stats);
-          return fail(MNMF_ENAN, "nmtf: non-finite update norm at iteration " + std::to_string(i + 1));
-        }
       }
       cw = 1 - cw;
       ch = 1 - ch;
@@ -1379,12 +1434,16 @@ class Engine : public ImplBase {
       if (fixed > 0) {
         if (i >= fixed) break;
       } else {
-        if (do_check && w_norm < thr && h_norm < thr && s_norm < thr) {   // :200
-          converged = 1;
-          break;
-        }
-        if (i > max_iter) break;                                          // :204
+        if (i > max_iter) break;                                          // :204 (the norms of this iteration: below)
       }
+    }
+    if (pending) {  // the loop ended on its iteration cap or count: the last iteration's norms       :200
+      const int r = resolve();
+      if (r != 0) {
+        (void)clock_stop(clk, stats);
+        return r;
+      }
+      if (fixed <= 0 && w_norm < thr && h_norm < thr && s_norm < thr) converged = 1;
     }
     MNMF_TRY(clock_stop(clk, stats));
     pt.collect(phase_ms);
