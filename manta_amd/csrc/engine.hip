@@ -79,6 +79,7 @@ struct Tune {
   int ld_align_small = 0;             // padding of factor rows with k <= 32 (elements); 0 = whole 128-byte lines (32 floats /
                                       // 16 doubles): C4, k = 20: 80-byte rows -> 128-byte rows, +10 %; C1, k = 10: +17 %
   int pack_exchange = 1;              // sharded runs: all-reduce only the k live columns of ld-padded rows
+  int wide_gram = 1;                  // symmetric Grams with 128 < ld <= 256: tiles split over the waves of a workgroup
   int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
@@ -106,6 +107,7 @@ struct Tune {
     tile_min_tiles_pct = (int)geti("MNMF_TILE_MIN_TILES_PCT", tile_min_tiles_pct);
     ld_align_small = (int)geti("MNMF_LD_ALIGN_SMALL", ld_align_small);
     xt_min_piece = (int)geti("MNMF_XT_MIN_PIECE", xt_min_piece);
+    wide_gram = (int)geti("MNMF_WIDE_GRAM", wide_gram);
     pack_exchange = (int)geti("MNMF_PACK_EXCHANGE", pack_exchange);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
@@ -749,6 +751,23 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  // symmetric Gram of a wide factor (5..8 column tiles): the waves of a workgroup split the tiles (gram_mfma.hpp)
+  template <int NT>
+  int gram_mfma_wide_launch(const float* A, const float* A2, int64_t rows, int ld, bool diff, float* out) {
+    const int64_t elems = (int64_t)ld * ld;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(2 * n_cus, cdiv(rows, 256)));
+    const int64_t rpb = round_up(cdiv(rows, blocks), 16);
+    const int64_t nb = cdiv(rows, rpb);
+    E_HIP(slab.ensure((size_t)nb * elems * sizeof(float)));
+    float* sl = slab.template as<float>();
+    if (diff) gram_mfma_wide_f32_kernel<NT, true><<<(unsigned)nb, 512, 0, st()>>>(A, A2, rows, ld, rpb, sl);
+    else gram_mfma_wide_f32_kernel<NT, false><<<(unsigned)nb, 512, 0, st()>>>(A, A2, rows, ld, rpb, sl);
+    E_LAUNCH();
+    slab_reduce_kernel<float><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(sl, nb, elems, out);
+    E_LAUNCH();
+    return 0;
+  }
+
   // out (ld x ld) = A^T B over rows;  diff: operands |A - A2|, |B - B2|
   int gram(const T* A, const T* A2, const T* B, const T* B2, int64_t rows, int ld, bool diff, T* out) {
     const int64_t elems = (int64_t)ld * ld;
@@ -761,6 +780,14 @@ class Engine : public ImplBase {
         const float* a = (const float*)A; const float* a2 = (const float*)A2;
         const float* b = (const float*)B; const float* b2 = (const float*)B2;
         float* o = (float*)out;
+        if (a == b && a2 == b2 && ld > 128 && tune.wide_gram) {
+          switch ((ld + 31) / 32) {
+            case 5: return gram_mfma_wide_launch<5>(a, a2, rows, ld, diff, o);
+            case 6: return gram_mfma_wide_launch<6>(a, a2, rows, ld, diff, o);
+            case 7: return gram_mfma_wide_launch<7>(a, a2, rows, ld, diff, o);
+            default: return gram_mfma_wide_launch<8>(a, a2, rows, ld, diff, o);
+          }
+        }
         switch ((ld + 31) / 32) {
           case 1: return gram_mfma_launch<1, 1>(a, a2, b, b2, rows, ld, diff, o);
           case 2: return gram_mfma_launch<2, 2>(a, a2, b, b2, rows, ld, diff, o);

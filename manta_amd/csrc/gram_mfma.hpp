@@ -150,6 +150,109 @@ __global__ __launch_bounds__(512) void gram_mfma_f32_kernel(const float* __restr
   }
 }
 
+// Wide symmetric Gram (129 <= ld <= 256, NT = 5..8 column tiles).  With one tile row per workgroup (the kernel above
+// with TR = 1) the factor is read NT/2 + 1 times from HBM -- 10.8 GB instead of 2 GB at k = 200 on 2.5M rows, which is
+// what bounded it.  Here a workgroup owns a row range and its 8 waves split the TILES of the upper triangle (3..5
+// each, contiguous in row-major order so they mostly share the A column): every wave walks all rows of the range, the
+// operand columns it needs come from L1 after the first wave touched them, and the factor leaves HBM once.  A wave
+// keeps its tiles in registers for the whole range and writes them (and their mirror images) straight to the block's
+// slab partial: no cross-wave reduction, no LDS.  Same fixed summation order on every run.
+template <int NT, bool DIFF>
+__global__ __launch_bounds__(512) void gram_mfma_wide_f32_kernel(const float* __restrict__ A, const float* __restrict__ A2,
+                                                                 int64_t rows, int ld, int64_t rpb, float* __restrict__ slab) {
+  constexpr int NTRI = NT * (NT + 1) / 2;
+  constexpr int MAXT = (NTRI + 7) / 8;
+  constexpr int UR = DIFF ? 2 : 4;  // row pairs per batch
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = lane & 31, rh = lane >> 5;
+  const int lo = wv * NTRI / 8, hi = (wv + 1) * NTRI / 8;  // this wave's tiles; hi - lo <= MAXT
+  int tt[MAXT], qq[MAXT], acol[MAXT], bcol[MAXT];
+  bool on[MAXT], aok[MAXT], bok[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    on[j] = lo + j < hi;
+    int rem = on[j] ? lo + j : lo, t = 0;
+    while (rem >= NT - t) {
+      rem -= NT - t;
+      ++t;
+    }
+    tt[j] = t;
+    qq[j] = t + rem;
+    const int ca = 32 * tt[j] + cl, cb = 32 * qq[j] + cl;
+    aok[j] = on[j] && ca < ld;
+    bok[j] = on[j] && cb < ld;
+    acol[j] = ca < ld ? ca : ld - 1;
+    bcol[j] = cb < ld ? cb : ld - 1;
+  }
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+  const int64_t r_end = (r_begin + rpb < rows) ? r_begin + rpb : rows;
+  if (r_begin >= r_end) return;
+  float an[UR][MAXT][DIFF ? 2 : 1], bn[UR][MAXT][DIFF ? 2 : 1];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      int64_t row = r0 + 2 * u + rh;
+      row = row < r_end ? row : r_end - 1;
+      const int64_t off = row * ld;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        an[u][j][0] = A[off + acol[j]];
+        bn[u][j][0] = A[off + bcol[j]];
+        if (DIFF) {
+          an[u][j][1] = A2[off + acol[j]];
+          bn[u][j][1] = A2[off + bcol[j]];
+        }
+      }
+    }
+  };
+  constexpr int64_t stride = 2 * UR;
+  fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += stride) {
+    float a[UR][MAXT], b[UR][MAXT];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const bool rok = r0 + 2 * u + rh < r_end;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        float x = an[u][j][0], y = bn[u][j][0];
+        if (DIFF) {
+          x = fabsf(x - an[u][j][1]);
+          y = fabsf(y - bn[u][j][1]);
+        }
+        a[u][j] = (rok && aok[j]) ? x : 0.f;
+        b[u][j] = (rok && bok[j]) ? y : 0.f;
+      }
+    }
+    if (r0 + stride < r_end) fetch(r0 + stride);
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc[j], 0, 0, 0);
+  }
+  // C/D layout of the 32x32 tile: lane holds column l&31, rows (e&3) + 8*(e>>2) + 4*(l>>5)
+  float* dst = slab + (int64_t)blockIdx.x * (int64_t)ld * ld;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    if (!on[j]) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int gi = 32 * tt[j] + (e & 3) + 8 * (e >> 2) + 4 * rh;
+      const int gj = 32 * qq[j] + cl;
+      if (gi < ld && gj < ld) {
+        const float v = acc[j][e];
+        dst[(int64_t)gi * ld + gj] = v;
+        if (qq[j] > tt[j]) dst[(int64_t)gj * ld + gi] = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rows x (k x k) products fused with the multiplicative update, on the matrix cores (fp32):
 //   acc = A1.G1 (+ A2.G2);  PROD: out = acc;  MU: out = upd*(num/(acc+eps));  MU_SQRT: upd*sqrt(num/(acc+eps))

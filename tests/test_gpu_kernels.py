@@ -109,7 +109,8 @@ def test_set_matrix_rejects_bad_input(engines):
 
 
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
-@pytest.mark.parametrize("rows,k", [(1, 3), (1000, 5), (5000, 50), (3001, 70), (777, 130), (300, 200)])
+@pytest.mark.parametrize("rows,k", [(1, 3), (1000, 5), (5000, 50), (3001, 70), (777, 130), (300, 200),
+                                     (40000, 160), (30011, 250), (2500, 136), (70001, 200)])
 def test_gram(engines, dtype, rows, k):
     eng = engines[dtype]
     rng = np.random.RandomState(rows + k)
@@ -121,7 +122,7 @@ def test_gram(engines, dtype, rows, k):
 
 
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
-@pytest.mark.parametrize("rows,k", [(1, 2), (999, 7), (4096, 50), (2000, 100), (500, 200)])
+@pytest.mark.parametrize("rows,k", [(1, 2), (999, 7), (4096, 50), (2000, 100), (500, 200), (20000, 160), (9999, 256)])
 def test_update(engines, dtype, rows, k):
     eng = engines[dtype]
     rng = np.random.RandomState(rows * 7 + k)
@@ -144,7 +145,7 @@ def test_update(engines, dtype, rows, k):
 def test_diff_norms(engines, dtype):
     eng = engines[dtype]
     rng = np.random.RandomState(5)
-    for rows, k in [(2000, 10), (300, 52), (50, 3)]:
+    for rows, k in [(2000, 10), (300, 52), (50, 3), (30000, 136), (8001, 200), (5000, 256)]:   # incl. the wide Gram kernel
         A, B = rng.rand(rows, k), rng.rand(rows, k)
         d = np.abs(A - B)
         tol = 1e-10 if dtype == "fp64" else 1e-5
