@@ -153,103 +153,133 @@ __global__ __launch_bounds__(512) void gram_mfma_f32_kernel(const float* __restr
 // Wide symmetric Gram (129 <= ld <= 256, NT = 5..8 column tiles).  With one tile row per workgroup (the kernel above
 // with TR = 1) the factor is read NT/2 + 1 times from HBM -- 10.8 GB instead of 2 GB at k = 200 on 2.5M rows, which is
 // what bounded it.  Here a workgroup owns a row range and its 8 waves split the TILES of the upper triangle (3..5
-// each, contiguous in row-major order so they mostly share the A column): every wave walks all rows of the range, the
-// operand columns it needs come from L1 after the first wave touched them, and the factor leaves HBM once.  A wave
-// keeps its tiles in registers for the whole range and writes them (and their mirror images) straight to the block's
-// slab partial: no cross-wave reduction, no LDS.  Same fixed summation order on every run.
+// each, contiguous in row-major order): every wave walks all rows of the range, the operand columns it needs come
+// from L1 after the first wave touched them, and the factor leaves HBM once.  The tile set of a wave is a compile-time
+// constant (one instantiation of the body per wave index), so each distinct operand column is loaded once per row
+// pair however many of the wave's tiles use it -- about one load per MFMA instead of two, which matters because this
+// kernel is bound by the vector-memory issue rate.  A wave keeps its tiles in registers for the whole range and
+// writes them (and their mirror images) straight to the block's slab partial: no cross-wave reduction, no LDS.
+// Same fixed summation order on every run.
+template <int NT>
+struct TriTile {  // tile idx (row-major over the upper triangle) -> (t, q)
+  static constexpr int row(int idx) {
+    int t = 0;
+    while (idx >= NT - t) {
+      idx -= NT - t;
+      ++t;
+    }
+    return t;
+  }
+  static constexpr int col(int idx) {
+    int t = 0;
+    while (idx >= NT - t) {
+      idx -= NT - t;
+      ++t;
+    }
+    return t + idx;
+  }
+};
+
+template <int NT, bool DIFF, int WV>
+__device__ inline void gram_wide_body(const float* __restrict__ A, const float* __restrict__ A2, int ld, int64_t r_begin,
+                                      int64_t r_end, float* __restrict__ dst) {
+  constexpr int NTRI = NT * (NT + 1) / 2;
+  constexpr int LO = WV * NTRI / 8, HI = (WV + 1) * NTRI / 8, N = HI - LO;
+  constexpr int UR = DIFF ? 2 : 4;  // row pairs per batch
+  if constexpr (N > 0) {
+    const int lane = threadIdx.x & 63;
+    const int cl = lane & 31, rh = lane >> 5;
+    // which operand columns this wave needs (compile time)
+    auto needed = [](int c) constexpr {
+      for (int j = 0; j < N; ++j)
+        if (TriTile<NT>::row(LO + j) == c || TriTile<NT>::col(LO + j) == c) return true;
+      return false;
+    };
+    int ccol[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int x = 32 * c + cl;
+      cok[c] = x < ld;
+      ccol[c] = cok[c] ? x : ld - 1;
+    }
+    f32x16 acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float vn[UR][NT][DIFF ? 2 : 1];
+    auto fetch = [&](int64_t r0) {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        int64_t row = r0 + 2 * u + rh;
+        row = row < r_end ? row : r_end - 1;
+        const int64_t off = row * ld;
+        static_for<NT>([&](auto c) {
+          if constexpr (needed(c.value)) {
+            vn[u][c.value][0] = A[off + ccol[c.value]];
+            if (DIFF) vn[u][c.value][1] = A2[off + ccol[c.value]];
+          }
+        });
+      }
+    };
+    constexpr int64_t stride = 2 * UR;
+    fetch(r_begin);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += stride) {
+      float v[UR][NT];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const bool rok = r0 + 2 * u + rh < r_end;
+        static_for<NT>([&](auto c) {
+          if constexpr (needed(c.value)) {
+            float x = vn[u][c.value][0];
+            if (DIFF) x = fabsf(x - vn[u][c.value][1]);
+            v[u][c.value] = (rok && cok[c.value]) ? x : 0.f;
+          }
+        });
+      }
+      if (r0 + stride < r_end) fetch(r0 + stride);
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        static_for<N>([&](auto j) {
+          constexpr int t = TriTile<NT>::row(LO + j.value), q = TriTile<NT>::col(LO + j.value);
+          acc[j.value] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u][t], v[u][q], acc[j.value], 0, 0, 0);
+        });
+    }
+    // C/D layout of the 32x32 tile: lane holds column l&31, rows (e&3) + 8*(e>>2) + 4*(l>>5)
+    static_for<N>([&](auto j) {
+      constexpr int t = TriTile<NT>::row(LO + j.value), q = TriTile<NT>::col(LO + j.value);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int gi = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * rh;
+        const int gj = 32 * q + cl;
+        if (gi < ld && gj < ld) {
+          const float x = acc[j.value][e];
+          dst[(int64_t)gi * ld + gj] = x;
+          if (q > t) dst[(int64_t)gj * ld + gi] = x;
+        }
+      }
+    });
+  }
+}
+
 template <int NT, bool DIFF>
 __global__ __launch_bounds__(512) void gram_mfma_wide_f32_kernel(const float* __restrict__ A, const float* __restrict__ A2,
                                                                  int64_t rows, int ld, int64_t rpb, float* __restrict__ slab) {
-  constexpr int NTRI = NT * (NT + 1) / 2;
-  constexpr int MAXT = (NTRI + 7) / 8;
-  constexpr int UR = DIFF ? 2 : 4;  // row pairs per batch
-  const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int cl = lane & 31, rh = lane >> 5;
-  const int lo = wv * NTRI / 8, hi = (wv + 1) * NTRI / 8;  // this wave's tiles; hi - lo <= MAXT
-  int tt[MAXT], qq[MAXT], acol[MAXT], bcol[MAXT];
-  bool on[MAXT], aok[MAXT], bok[MAXT];
-#pragma unroll
-  for (int j = 0; j < MAXT; ++j) {
-    on[j] = lo + j < hi;
-    int rem = on[j] ? lo + j : lo, t = 0;
-    while (rem >= NT - t) {
-      rem -= NT - t;
-      ++t;
-    }
-    tt[j] = t;
-    qq[j] = t + rem;
-    const int ca = 32 * tt[j] + cl, cb = 32 * qq[j] + cl;
-    aok[j] = on[j] && ca < ld;
-    bok[j] = on[j] && cb < ld;
-    acol[j] = ca < ld ? ca : ld - 1;
-    bcol[j] = cb < ld ? cb : ld - 1;
-  }
-  f32x16 acc[MAXT];
-#pragma unroll
-  for (int j = 0; j < MAXT; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   const int64_t r_begin = (int64_t)blockIdx.x * rpb;
   const int64_t r_end = (r_begin + rpb < rows) ? r_begin + rpb : rows;
-  if (r_begin >= r_end) return;
-  float an[UR][MAXT][DIFF ? 2 : 1], bn[UR][MAXT][DIFF ? 2 : 1];
-  auto fetch = [&](int64_t r0) {
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      int64_t row = r0 + 2 * u + rh;
-      row = row < r_end ? row : r_end - 1;
-      const int64_t off = row * ld;
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) {
-        an[u][j][0] = A[off + acol[j]];
-        bn[u][j][0] = A[off + bcol[j]];
-        if (DIFF) {
-          an[u][j][1] = A2[off + acol[j]];
-          bn[u][j][1] = A2[off + bcol[j]];
-        }
-      }
-    }
-  };
-  constexpr int64_t stride = 2 * UR;
-  fetch(r_begin);
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += stride) {
-    float a[UR][MAXT], b[UR][MAXT];
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      const bool rok = r0 + 2 * u + rh < r_end;
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) {
-        float x = an[u][j][0], y = bn[u][j][0];
-        if (DIFF) {
-          x = fabsf(x - an[u][j][1]);
-          y = fabsf(y - bn[u][j][1]);
-        }
-        a[u][j] = (rok && aok[j]) ? x : 0.f;
-        b[u][j] = (rok && bok[j]) ? y : 0.f;
-      }
-    }
-    if (r0 + stride < r_end) fetch(r0 + stride);
-#pragma unroll
-    for (int u = 0; u < UR; ++u)
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc[j], 0, 0, 0);
-  }
-  // C/D layout of the 32x32 tile: lane holds column l&31, rows (e&3) + 8*(e>>2) + 4*(l>>5)
+  if (r_begin >= r_end) return;  // never happens: the host sizes the grid to cdiv(rows, rpb)
   float* dst = slab + (int64_t)blockIdx.x * (int64_t)ld * ld;
-#pragma unroll
-  for (int j = 0; j < MAXT; ++j) {
-    if (!on[j]) continue;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int gi = 32 * tt[j] + (e & 3) + 8 * (e >> 2) + 4 * rh;
-      const int gj = 32 * qq[j] + cl;
-      if (gi < ld && gj < ld) {
-        const float v = acc[j][e];
-        dst[(int64_t)gi * ld + gj] = v;
-        if (qq[j] > tt[j]) dst[(int64_t)gj * ld + gi] = v;
-      }
-    }
+  switch (wv) {  // one body per wave index: its tile set is a compile-time constant
+    case 0: gram_wide_body<NT, DIFF, 0>(A, A2, ld, r_begin, r_end, dst); break;
+    case 1: gram_wide_body<NT, DIFF, 1>(A, A2, ld, r_begin, r_end, dst); break;
+    case 2: gram_wide_body<NT, DIFF, 2>(A, A2, ld, r_begin, r_end, dst); break;
+    case 3: gram_wide_body<NT, DIFF, 3>(A, A2, ld, r_begin, r_end, dst); break;
+    case 4: gram_wide_body<NT, DIFF, 4>(A, A2, ld, r_begin, r_end, dst); break;
+    case 5: gram_wide_body<NT, DIFF, 5>(A, A2, ld, r_begin, r_end, dst); break;
+    case 6: gram_wide_body<NT, DIFF, 6>(A, A2, ld, r_begin, r_end, dst); break;
+    default: gram_wide_body<NT, DIFF, 7>(A, A2, ld, r_begin, r_end, dst); break;
   }
 }
 
