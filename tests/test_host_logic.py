@@ -243,3 +243,24 @@ def test_tfidf_flatten_documents_and_reduceat_lengths():
         tfidf._reduceat_lengths(torch.tensor([0, 2, 2]), torch.tensor([0, 1, 1]), torch.tensor([2], dtype=torch.int32))
     with pytest.raises(IndexError):
         tfidf.flatten_documents([[2 ** 40]])
+
+
+def test_init_device_dense_helpers_on_cpu():
+    """The tall-skinny helpers of manta_amd/init_device.py are plain torch: slab-split A^T.B equals the direct product,
+    CholeskyQR2 gives an orthonormal basis of a well-conditioned block and the Householder fallback drops dependent
+    columns of a rank-deficient one."""
+    import torch
+    from manta_amd.init_device import _orthonormal_columns, _tsgemm
+
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn((10007, 13), generator=g, dtype=torch.float64)
+    B = torch.randn((10007, 5), generator=g, dtype=torch.float64)
+    assert torch.allclose(_tsgemm(A, B), A.t() @ B, rtol=1e-12, atol=1e-9)
+    assert torch.allclose(_tsgemm(A[:100], B[:100]), A[:100].t() @ B[:100], rtol=1e-12, atol=1e-12)   # below one slab
+    Q = _orthonormal_columns(A)
+    assert Q.shape == A.shape and torch.allclose(Q.t() @ Q, torch.eye(13, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(Q @ (Q.t() @ A), A, atol=1e-9)                      # same column space
+    D = torch.cat([A[:, :4], A[:, :2] @ torch.randn((2, 3), generator=g, dtype=torch.float64)], dim=1)   # rank 4 of 7
+    Qd = _orthonormal_columns(D)
+    assert Qd.shape[1] == 4 and torch.allclose(Qd.t() @ Qd, torch.eye(4, dtype=torch.float64), atol=1e-10)
+    assert _orthonormal_columns(D, drop=False) is None
