@@ -1,5 +1,5 @@
 """Throughput of the device TF-IDF builder on a synthetic corpus shaped like BASELINE.json configs[1]
-(1M documents x 100k words, ~100 tokens per document), tokens resident in HBM, against the CPU oracle on a sample.
+(1M documents x 100k words, ~100 tokens per document), tokens resident in HBM, next to the CPU oracle on a sample (timed by tests/cpu_tfidf_baseline.py in its own process).
 
     python tools/bench_tfidf.py [--docs 1000000] [--vocab 100000] [--len 100] [--cpu-docs 20000]
 """
@@ -56,16 +56,14 @@ def main():
     out.update(nnz=nnz, term_counts_ms=round(t_counts * 1e3, 2), global_sort_ms=round(t_sort * 1e3, 2),
                tfidf_total_ms=round(t_full * 1e3, 2), tokens_per_s=round(tokens.numel() / t_full),
                term_counts_alg_GBps=round(alg / t_counts / 1e9, 1))
-    # CPU oracle on the first cpu_docs documents
-    from oracle import tfidf_oracle as to
-    n = min(a.cpu_docs, a.docs)
-    tk, pp = tokens[: int(ptr[n])].cpu().numpy(), ptr[: n + 1].cpu().numpy()
-    docs = [tk[pp[i]:pp[i + 1]] for i in range(n)]
-    docs[-1] = np.append(docs[-1], a.vocab - 1)
-    t = time.perf_counter()
-    to.tf_idf_english(n, a.vocab, docs)
-    t_cpu = time.perf_counter() - t
-    out.update(cpu_oracle_docs=n, cpu_oracle_tokens_per_s=round(int(pp[n]) / t_cpu), cpu_oracle_s=round(t_cpu, 2))
+    # CPU leg: the oracle on a bounded sample of the same distribution, in a process of its own under tests/
+    # (only test code imports the oracle)
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(here, "tests", "cpu_tfidf_baseline.py"), "--docs", str(min(a.cpu_docs, a.docs)),
+                        "--vocab", str(a.vocab), "--len", str(a.len)], capture_output=True, text=True)
+    if r.returncode == 0:
+        out.update(json.loads(r.stdout.strip().splitlines()[-1]))
     print(json.dumps(out))
     eng.close()
 
