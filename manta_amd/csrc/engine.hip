@@ -67,7 +67,7 @@ struct DevBuf {
 struct Tune {
   int64_t x_q = 512;                  // target nnz per segment, X stream
   int64_t xt_q = 128;                 // target nnz per segment, X^T stream (small: one XCD stays inside one document block)
-  int64_t xt_block_bytes = 2 << 20;   // bytes of W rows per document block of X^T
+  int64_t xt_block_bytes = 4 << 20;   // bytes of W rows per document block of X^T (upper limit; see spmm())
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
@@ -638,9 +638,13 @@ class Engine : public ImplBase {
     const int lds_ld = ld + VEC;
     MNMF_TRY(ensure_prepared());
     if (&M == &Xt) {
-      // document block = rows of W that fit about half of one XCD's 4 MiB L2
+      // document block = rows of W worth about one XCD's 4 MiB L2 (measured optimum at C2 / C3 / C4: 4 MiB against
+      // 2 MiB +0.6 / +2.7 / +1.9 %, 8 MiB -4 %: fewer pieces and carries against L2 residency), but never so large that
+      // a small matrix is left with fewer than about four blocks (C1, 2.5 MB of W: one block -13 %, four or more +9 %)
+      const int64_t w_bytes = std::max<int64_t>(m, 1) * ld * (int64_t)sizeof(T);
+      const int64_t block_bytes = std::min<int64_t>(tune.xt_block_bytes, std::max<int64_t>((int64_t)256 << 10, w_bytes / 4));
       int bs = 8;
-      while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= tune.xt_block_bytes) ++bs;
+      while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= block_bytes) ++bs;
       // tile stream for the most frequent words: documents per tile = what one workgroup's LDS holds
       int n_hot = 0, tile_rows = 0;
       if (vmap() && tune.xt_hot_words > 0 && nnz >= tune.hot_min_nnz) {
