@@ -36,6 +36,20 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0
 L1_GATHER_PEAK_GBS = 28000.0   # measured on MI355X with tools/l1_probe.hip (profiles/r01_l1_gather_probe.txt)
+LDS_READ_PEAK_GBS = 150000.0   # ds_read_b128, every CU streaming (MI355X_MICROARCH.md, LDS)
+
+
+def source_fingerprint():
+    """Hash of the kernel sources the library is built from: counter summaries under profiles/ carry the fingerprint
+    of the build they were measured on, and a summary of another build is not quoted as this build's traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "manta_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(config, dtype, direction):
@@ -49,9 +63,13 @@ def pmc_traffic(config, dtype, direction):
     if not files or dtype != "fp32":
         return None, None
     try:
-        rows = json.load(open(files[-1]))
+        doc = json.load(open(files[-1]))
     except (OSError, ValueError):
         return None, None
+    # summaries written since round 2 name the build they were measured on; anything else is not this build's traffic
+    if not isinstance(doc, dict) or doc.get("source_sha") != source_fingerprint():
+        return None, "stale: " + os.path.relpath(files[-1], ROOT) + " was measured on another build of the kernels"
+    rows = doc["kernels"]
     total, hit = 0.0, False
     for r in rows:
         name = r.get("kernel", "")
@@ -83,8 +101,26 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (decided
+    before anything touches the GPU; this process only relays the ranks' output and exit code)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -99,8 +135,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -211,7 +246,7 @@ def main():
     dom = max(alg_bytes, key=lambda n: phases.get(n, 0.0))
     dom_ms = phases[dom]
     achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    ld = (k + 3) // 4 * 4 if k <= 32 else (k + 15) // 16 * 16   # the engine's padded row width
+    ld = eng.row_stride(k)                                      # the engine's padded row width (mnmf_row_stride)
     custom = bool(args.m or args.V or args.k or args.density)   # size overrides: the committed counter passes do not apply
     traffic, traffic_src = pmc_traffic(args.config, args.dtype, 1 if dom == "spmm_xt" else 0) \
         if world == 1 and not custom else (None, None)
@@ -225,6 +260,9 @@ def main():
                 "gather_bound": {"bytes_per_launch": gather_bytes, "achieved_GBps": round(gather_bytes / (dom_ms * 1e-3) / 1e9, 1),
                                  "l1_hit_peak_GBps": L1_GATHER_PEAK_GBS,
                                  "frac": round(gather_bytes / (dom_ms * 1e-3) / 1e9 / L1_GATHER_PEAK_GBS, 4)},
+                # the same gather if every factor row came out of LDS (ds_read_b128 at the chip-wide rate)
+                "lds_bound": {"bytes_per_launch": gather_bytes, "lds_read_peak_GBps": LDS_READ_PEAK_GBS,
+                              "frac": round(gather_bytes / (dom_ms * 1e-3) / 1e9 / LDS_READ_PEAK_GBS, 4)},
                 "phase_ms_per_iter": {n: round(v, 4) for n, v in phases.items() if v > 0},
                 "iteration_bytes_model": st.bytes_model,
                 "iteration_frac_of_hbm": round(st.bytes_model * value / world / 1e9 / HBM_PEAK_GBS, 4)}

@@ -85,6 +85,10 @@ void mnmf_destroy(mnmf_ctx* ctx);
 const char* mnmf_last_error(const mnmf_ctx* ctx);
 const char* mnmf_version(void);
 
+/* Elements per row of a k-column factor in the engine's internal (zero padded) layout for this context's dtype: what
+ * one nnz of X gathers.  Measurement helper (bench.py's gather-traffic bound); no counterpart in the reference. */
+int mnmf_row_stride(const mnmf_ctx* ctx, int k);
+
 /* Install (or clear, fn==NULL) the all-reduce hook.  `n_ranks` is informational (byte model). */
 int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ranks);
 
@@ -120,6 +124,16 @@ int mnmf_gram(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, 
  * nmf_projective_basic.py:76-79.  A, num, out: rows x k; G, G2: k x k. */
 int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* num, const void* G,
                 const void* G2, double eps, int sqrt_mode, void* out);
+/* mnmf_gram for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  NO counterpart in the reference (nor is it a SURVEY.md section 8 row); same arguments and result as
+ * mnmf_gram (out = A^T . B over `rows` rows, B == NULL: A^T A; A, B: rows x k row-major, out: k x k, device pointers,
+ * context dtype).  It calls no hipMalloc / hipFree or allocating library routine and does not synchronise: two kernels
+ * are enqueued on the context's stream and the call returns.  The partial Grams live in a static 8 MiB device array of
+ * the library (one copy per GPU, held until the process ends), so k <= 256 (MNMF_EINVAL beyond, with a message) and
+ * every call on a GPU shares that array: calls that overlap on one GPU (two streams, two contexts, two threads) race;
+ * calls ordered on one stream do not.  Nothing in the array has to be zero on entry.  Summation order differs from
+ * mnmf_gram's (fp32: vector ALUs here, matrix cores there): results agree to rounding, not bit for bit. */
+int mnmf_gram_static(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, void* out);
 /* sigma_max(|A - B|) (norm_kind 0, `norm_func(np.abs(w - w_old), 2)`, nmf_basic.py:52) or its
  * Frobenius norm (norm_kind 1, nmtf.py:179) for rows x k matrices. */
 int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind,
@@ -130,6 +144,12 @@ int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void
  * idx_out: groups x n int32 (device; -1 past the end), val_out: groups x n (device). */
 int mnmf_topk(mnmf_ctx* ctx, int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx_out,
               void* val_out);
+/* NMTF topic-relationship summary, the computation inside s_matrix_confusion (nmtf/nmtf.py:62-80): for every column i
+ * of the device matrix S (k x k row-major, context dtype, k <= 1024) the row of its maximum (np.argmax: the first one on
+ * ties) and that value, ordered by value descending (`np.argsort(max_values)[::-1]`; equal values: larger column
+ * first).  Entry r of the outputs (device, k each) describes the r-th strongest coupling: col_out[r] = the column i,
+ * row_out[r] = argmax row, val_out[r] = S[row, i].  Drains the stream. */
+int mnmf_s_confusion(mnmf_ctx* ctx, int k, const void* S, int32_t* col_out, int32_t* row_out, void* val_out);
 /* -- TF-IDF construction (the producer of X) --------------------------- */
 /* Term-count matrix of a tokenised corpus, replacing the Counter / lil_matrix loop of
  * tfidf_english_calculator.py:80-87 and tfidf_turkish_calculator.py:37-45.  doc_ptr: int64[m+1] (device), document d

@@ -40,6 +40,7 @@ SIGNATURES = {
     "mnmf_destroy": (None, [C.c_void_p]),
     "mnmf_last_error": (C.c_char_p, [C.c_void_p]),
     "mnmf_version": (C.c_char_p, []),
+    "mnmf_row_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "mnmf_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]),
     "mnmf_set_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mnmf_run_nmf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),
@@ -47,9 +48,11 @@ SIGNATURES = {
     "mnmf_run_nmtf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),
     "mnmf_spmm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mnmf_gram": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnmf_gram_static": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnmf_update": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "mnmf_diff_norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "mnmf_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mnmf_s_confusion": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnmf_tfidf_count_terms": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
     "mnmf_tfidf_fill_terms": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

@@ -9,10 +9,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmnmf.so")
 OBJ = os.path.join(CSRC, "_obj")
-# translation unit -> the files it includes
-SOURCES = {
-    "engine.hip": ["ctx.hpp", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp", "topk.hpp", "histogram.hpp"],
-    "tfidf.hip": ["ctx.hpp", "common.hpp", "histogram.hpp"],
+_ENGINE_DEPS = ["ctx.hpp", "impl_base.hpp", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp",
+                "topk.hpp", "histogram.hpp"]
+# object -> (source, extra flags, the files it includes).  Engine<float> and Engine<double> are separate objects so
+# the four compiles run side by side.
+UNITS = {
+    "engine_f32.o": ("engine.hip", ["-DMNMF_ENGINE_DTYPE=32"], _ENGINE_DEPS),
+    "engine_f64.o": ("engine.hip", ["-DMNMF_ENGINE_DTYPE=64"], _ENGINE_DEPS),
+    "capi.o": ("capi.hip", [], ["ctx.hpp", "impl_base.hpp", "common.hpp", "dense.hpp", "eig.hpp", "sparse_prep.hpp"]),
+    "tfidf.o": ("tfidf.hip", [], ["ctx.hpp", "common.hpp", "histogram.hpp"]),
 }
 HEADER = os.path.join(HERE, "..", "include", "mnmf.h")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
@@ -32,12 +37,13 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def _deps(src: str):
-    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in SOURCES[src]] + [HEADER]
+def _deps(obj: str):
+    src, _, incs = UNITS[obj]
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in incs] + [HEADER]
 
 
 def needs_build() -> bool:
-    return any(_stale(LIB, _deps(src)) for src in SOURCES)
+    return any(_stale(LIB, _deps(obj)) for obj in UNITS)
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
@@ -45,15 +51,18 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    objs, jobs = [], []
+    for name, (src, extra, _) in UNITS.items():
+        obj = os.path.join(OBJ, name)
         objs.append(obj)
-        if force or _stale(obj, _deps(src)):
-            cmd = [_hipcc()] + FLAGS + ["-c", "-o", obj, src]
+        if force or _stale(obj, _deps(name)):
+            cmd = [_hipcc()] + FLAGS + extra + ["-c", "-o", obj, src]
             if verbose:
                 print("[manta_amd] " + " ".join(cmd), flush=True)
-            subprocess.run(cmd, cwd=CSRC, check=True)
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print("[manta_amd] " + " ".join(cmd), flush=True)

@@ -243,6 +243,42 @@ __global__ void kxk_transpose_kernel(const T* __restrict__ A, T* __restrict__ B,
   B[idx] = A[(idx % n) * n + idx / n];
 }
 
+// NMTF topic-relationship summary (s_matrix_confusion, nmtf.py:62-80): for every column i of S (k x k, leading
+// dimension lds) the row of its maximum (first one on ties, as np.argmax) and that value; the columns are then
+// ranked by value, descending (equal values: larger column first = the reverse of a stable ascending argsort).
+// One workgroup; thread i owns column i (k <= blockDim.x).  Outputs are in rank order.
+template <typename T>
+__global__ void s_confusion_kernel(const T* __restrict__ S, int k, int lds, int32_t* __restrict__ col_out,
+                                   int32_t* __restrict__ row_out, T* __restrict__ val_out) {
+  extern __shared__ unsigned char s_conf_smem[];
+  T* best = reinterpret_cast<T*>(s_conf_smem);
+  const int i = threadIdx.x;
+  T v = T(0);
+  int arg = 0;
+  if (i < k) {
+    v = S[i];
+    for (int r = 1; r < k; ++r) {
+      const T x = S[(int64_t)r * lds + i];
+      if (x > v) {
+        v = x;
+        arg = r;
+      }
+    }
+    best[i] = v;
+  }
+  __syncthreads();
+  if (i < k) {
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const T x = best[j];
+      rank += (x > v || (x == v && j > i)) ? 1 : 0;
+    }
+    col_out[rank] = i;
+    row_out[rank] = arg;
+    val_out[rank] = v;
+  }
+}
+
 // k x k (dense) -> ld x ld zero padded.
 template <typename T>
 __global__ void pad_sq_kernel(const T* __restrict__ in, int k, int ld, T* __restrict__ out) {

@@ -22,22 +22,7 @@
 
 using namespace mnmf;
 
-struct ImplBase {
-  virtual ~ImplBase() {}
-  virtual int set_matrix(int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
-                         const void* vals, int on_device) = 0;
-  virtual int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
-  virtual int run_pnmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
-  virtual int run_nmtf(int k, void* W, void* S, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
-  virtual int k_spmm(int transpose, int k, const void* B, void* out) = 0;
-  virtual int k_gram(int64_t rows, int k, const void* A, const void* B, void* out) = 0;
-  virtual int k_update(int64_t rows, int k, const void* A, const void* num, const void* G, const void* G2,
-                       double eps, int sqrt_mode, void* out) = 0;
-  virtual int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) = 0;
-  virtual int hook_changed() = 0;
-  virtual int k_topk(int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx, void* val) = 0;
-};
-
+#include "impl_base.hpp"
 #include "ctx.hpp"
 
 namespace {
@@ -90,6 +75,8 @@ struct Tune {
   int fuse_grams = 1;                 // Grams of the new factor / of |new - old| inside the update kernel (k <= 64)
   int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
+  int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
+  int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
     x_q = geti("MNMF_X_Q", x_q);
@@ -118,6 +105,8 @@ struct Tune {
     mfma_gram = (int)geti("MNMF_MFMA_GRAM", mfma_gram);
     mfma_rk = (int)geti("MNMF_MFMA_RK", mfma_rk);
     fuse_grams = (int)geti("MNMF_FUSE_GRAMS", fuse_grams);
+    lds_pad = (int)geti("MNMF_LDS_PAD", lds_pad);
+    force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
   }
 };
 
@@ -196,9 +185,10 @@ class Engine : public ImplBase {
   std::vector<int64_t> h_rowptr;
   DevBuf d_rowptr;
   // vocabulary renumbering by descending document frequency (identical on every rank)
-  bool prepared = false;
+  bool prepared = false;     // ensure_prepared() has run to its end for the current matrix and hook
+  bool renumbered = false;   // ... and the vocabulary is renumbered (a decision every rank takes alike)
   DevBuf d_newid, d_order;   // int32 newid[old], uint32 order[new]
-  const int32_t* vmap() const { return (prepared && tune.permute_vocab && nnz > 0) ? d_newid.template as<int32_t>() : nullptr; }
+  const int32_t* vmap() const { return (prepared && renumbered) ? d_newid.template as<int32_t>() : nullptr; }
   int n_cus = 256;
   // solver workspaces
   DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD, ar_pack;
@@ -218,6 +208,8 @@ class Engine : public ImplBase {
     const int a = (k > 32 && tune.ld_align > 4) ? tune.ld_align : small;
     return (int)round_up(k, a);
   }
+
+  int row_stride(int k) const override { return k > 0 ? ld_of(k) : 0; }
 
   int fail(int code, const std::string& msg) {
     ctx->fail(code, msg);
@@ -269,6 +261,7 @@ class Engine : public ImplBase {
     Xt = StreamMat<T>();
     Xth = StreamMat<T>();
     prepared = false;
+    renumbered = false;
     X.rows = m;
     X.tab_rows = V;
     X.nnz = nnz;
@@ -334,10 +327,15 @@ class Engine : public ImplBase {
   // Renumber the vocabulary by descending document frequency (ties: ascending id), so that the rows of
   // H^T that are gathered most are the first rows.  df is summed over ranks through the all-reduce hook
   // before sorting, so every rank derives the same numbering (H^T is replicated and all-reduced).
+  // A rank whose shard has no nnz still takes part in the df exchange (with zeros) and still builds the maps: the
+  // other ranks' first collective is this one, and H^T must be in the same row order everywhere.
   int ensure_prepared() {
     if (prepared) return 0;
-    prepared = true;
-    if (!tune.permute_vocab || nnz == 0) return 0;
+    renumbered = false;
+    if (!tune.permute_vocab || (nnz == 0 && !ctx->ar)) {
+      prepared = true;
+      return 0;
+    }
     const int TB = 256;
     DevBuf df, key, key_out, iota, tmp;
     E_HIP(df.ensure((size_t)V * 4));
@@ -347,7 +345,8 @@ class Engine : public ImplBase {
     E_HIP(d_newid.ensure((size_t)V * 4));
     E_HIP(d_order.ensure((size_t)V * 4));
     MNMF_TRY(clear_x_flags());
-    MNMF_TRY(column_histogram(df.template as<int32_t>()));
+    if (nnz > 0) MNMF_TRY(column_histogram(df.template as<int32_t>()));
+    else E_HIP(hipMemsetAsync(df.p, 0, (size_t)V * 4, st()));
     df_to_key_kernel<T><<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(df.template as<int32_t>(), V, key.template as<T>(), iota.template as<uint32_t>());
     E_LAUNCH();
     MNMF_TRY(allreduce(key.template as<T>(), V));
@@ -359,13 +358,17 @@ class Engine : public ImplBase {
                                          d_order.template as<uint32_t>(), (size_t)V, 0u, (unsigned)(8 * sizeof(T)), st()));
     invert_perm_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(d_order.template as<uint32_t>(), V, d_newid.template as<int32_t>());
     E_LAUNCH();
-    remap_cols_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, d_newid.template as<int32_t>());
-    E_LAUNCH();
+    if (nnz > 0) {
+      remap_cols_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, d_newid.template as<int32_t>());
+      E_LAUNCH();
+    }
     E_HIP(hipStreamSynchronize(st()));
     Xt.built = false;
     Xt.seg_q = -1;
     Xth.built = false;
     Xth.seg_q = -1;
+    renumbered = true;
+    prepared = true;   // only now: a failure above leaves the matrix as it was and the next call tries again
     return 0;
   }
 
@@ -373,7 +376,7 @@ class Engine : public ImplBase {
   int hook_changed() override {
     if (!have_matrix || !prepared) return 0;
     E_HIP(hipSetDevice(ctx->device));
-    if (tune.permute_vocab && nnz > 0) {
+    if (renumbered && nnz > 0) {
       MNMF_TRY(clear_x_flags());
       // back to the caller's ids: order[new] = old, as int32 map
       remap_cols_kernel<<<(unsigned)cdiv(nnz, 256), 256, 0, st()>>>(X.cols.template as<uint32_t>(), nnz, d_order.template as<int32_t>());
@@ -381,6 +384,7 @@ class Engine : public ImplBase {
       E_HIP(hipStreamSynchronize(st()));
     }
     prepared = false;
+    renumbered = false;
     Xt.built = false;
     Xt.seg_q = -1;
     Xth.built = false;
@@ -569,21 +573,24 @@ class Engine : public ImplBase {
   }
 
   // ------------------------------------------------------------------ kernels
+  // B, out and the carry buffer are already offset to the first of the `nc` columns this launch handles
   template <int LPR, int VPL>
-  int spmm_launch(StreamMat<T>& M, const T* B, int ld, T* out, int hot, int lds_ld) {
+  int spmm_launch(StreamMat<T>& M, const T* B, int ld, int nc, int c0, T* out, int hot, int lds_ld) {
     constexpr int NG = kWave / LPR;
+    constexpr size_t kLdsSlack = (size_t)LPR * VPL * 16;   // idle lanes read past the last row (spmm.hpp, lbytes)
     const int64_t waves = cdiv(M.n_seg, NG);
-    const size_t tab_bytes = (size_t)M.tab_rows * ld * sizeof(T);
-    const bool wide = M.tab_rows >= ((int64_t)1 << 24) || tab_bytes >= ((size_t)1 << 32) ||
+    const size_t tab_bytes = ((size_t)M.tab_rows * ld - (size_t)c0) * sizeof(T);
+    const bool wide = tune.force_wide || M.tab_rows >= ((int64_t)1 << 24) || tab_bytes >= ((size_t)1 << 32) ||
                       (size_t)ld * sizeof(T) >= ((size_t)1 << 24);
+    T* carry = M.carry.template as<T>() + c0;
     SpmmArgs<T> a{M.seg_start.template as<int64_t>(), M.seg_len.template as<int32_t>(), M.seg_info.template as<int32_t>(), M.n_seg,
                   M.cols.template as<uint32_t>(), M.vals.template as<T>(), M.dest.template as<int32_t>(), M.n_dest,
-                  B, ld, out, M.carry.template as<T>(), hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes,
+                  B, ld, nc, out, carry, hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes,
                   M.tile_first.template as<int32_t>(), (int)M.n_tiles, M.tile_rows, M.tab_rows};
     if (&M == &Xth) {
       if (waves > 0) {  // tile stream: every gather is an LDS read (indices are local to the tile)
         auto kern = spmm_stream_kernel<T, LPR, VPL, 1, SPMM_TILE, false>;
-        const size_t lds_bytes = (size_t)M.tile_rows * lds_ld * sizeof(T);
+        const size_t lds_bytes = (size_t)M.tile_rows * lds_ld * sizeof(T) + kLdsSlack;
         E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         a.hot_rows = 0;
         const int wgs = std::max(1, tune.tile_wgs_per_cu);  // workgroups per CU: one stages while another computes
@@ -592,7 +599,7 @@ class Engine : public ImplBase {
       }
     } else if (waves > 0 && hot > 0 && !wide) {
       auto kern = spmm_stream_kernel<T, LPR, VPL, 0, SPMM_HOT, false>;
-      const size_t lds_bytes = (size_t)hot * lds_ld * sizeof(T);
+      const size_t lds_bytes = (size_t)hot * lds_ld * sizeof(T) + kLdsSlack;
       E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       kern<<<(unsigned)n_cus, 1024, lds_bytes, st()>>>(a);
       E_LAUNCH();
@@ -614,14 +621,14 @@ class Engine : public ImplBase {
     if (M.n_fix_long > 0) {
       // few rows with very long lists (tile stream): 16 waves per row; many rows with moderate lists: 4
       if (M.n_fix_long <= (int64_t)8 * n_cus)
-        spmm_fixup_long_kernel<T, LPR, VPL, 16><<<(unsigned)M.n_fix_long, 1024, 0, st()>>>(fr, ff, fc, M.carry.template as<T>(), ld, out);
+        spmm_fixup_long_kernel<T, LPR, VPL, 16><<<(unsigned)M.n_fix_long, 1024, 0, st()>>>(fr, ff, fc, carry, ld, nc, out);
       else
-        spmm_fixup_long_kernel<T, LPR, VPL, 4><<<(unsigned)M.n_fix_long, 256, 0, st()>>>(fr, ff, fc, M.carry.template as<T>(), ld, out);
+        spmm_fixup_long_kernel<T, LPR, VPL, 4><<<(unsigned)M.n_fix_long, 256, 0, st()>>>(fr, ff, fc, carry, ld, nc, out);
       E_LAUNCH();
     }
     if (M.n_fix > M.n_fix_long) {
       const int64_t n = M.n_fix - M.n_fix_long, o = M.n_fix_long;
-      spmm_fixup_kernel<T, LPR, VPL><<<(unsigned)cdiv(n, 4), 256, 0, st()>>>(fr + o, ff + o, fc + o, n, M.carry.template as<T>(), ld, out);
+      spmm_fixup_kernel<T, LPR, VPL><<<(unsigned)cdiv(n, 4), 256, 0, st()>>>(fr + o, ff + o, fc + o, n, carry, ld, nc, out);
       E_LAUNCH();
     }
     return 0;
@@ -630,12 +637,30 @@ class Engine : public ImplBase {
   // out (M.rows x ld) = M . B   (B: M.tab_rows x ld)
   int spmm(StreamMat<T>& M, const T* B, int ld, T* out) {
     constexpr int VEC = VecOf<T>::N;
+    if (ld % VEC != 0) return fail(MNMF_EINVAL, "spmm: the leading dimension must be a whole number of 16-byte vectors");
+    if (ld / VEC > 128) {
+      // A wave covers at most 128 vectors of a row (512 floats / 256 doubles): wider factors go through the plain
+      // stream in column chunks of that width -- the nnz stream is read once per chunk, nothing else changes.
+      MNMF_TRY(ensure_prepared());
+      if (&M == &Xt) {
+        int bs = 8;
+        while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= tune.xt_block_bytes) ++bs;
+        MNMF_TRY(ensure_xt(bs, 0, 0));
+      }
+      MNMF_TRY(spmm_stream(M, B, ld, out, 64, 2, 1, ld, 1));   // segments, carry buffer, empty rows
+      for (int c0 = 0; c0 < ld; c0 += 128 * VEC) {
+        const int nc = std::min(128 * VEC, ld - c0);
+        const int nv = nc / VEC;
+        if (nv > 64) MNMF_TRY((spmm_launch<64, 2>(M, B + c0, ld, nc, c0, out + c0, 0, ld)));
+        else MNMF_TRY(spmm_dispatch(M, B + c0, ld, nc, c0, out + c0, 0, ld, 1, std::max(4, pow2_ceil(nv))));
+      }
+      return 0;
+    }
     const int nvec = ld / VEC;
-    if (ld % VEC != 0 || nvec > 128) return fail(MNMF_EINVAL, "spmm: unsupported k (max 512 f32 / 256 f64)");
     const int vpl = nvec > 64 ? 2 : 1;
     const int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
     const int ng = kWave / lpr;
-    const int lds_ld = ld + VEC;
+    const int lds_ld = ld + lds_pad_for(ld, lpr);
     MNMF_TRY(ensure_prepared());
     if (&M == &Xt) {
       // document block = rows of W worth about one XCD's 4 MiB L2 (measured optimum at C2 / C3 / C4: 4 MiB against
@@ -719,14 +744,33 @@ class Engine : public ImplBase {
       hot = (int)std::min<int64_t>(M.tab_rows, tune.hot_lds_bytes / ((int64_t)lds_ld * (int64_t)sizeof(T)));
       if (hot < 16) hot = 0;
     }
-    if (vpl == 2) return spmm_launch<64, 2>(M, B, ld, out, hot, lds_ld);
+    return spmm_dispatch(M, B, ld, ld, 0, out, hot, lds_ld, vpl, lpr);
+  }
+
+  int spmm_dispatch(StreamMat<T>& M, const T* B, int ld, int nc, int c0, T* out, int hot, int lds_ld, int vpl, int lpr) {
+    if (vpl == 2) return spmm_launch<64, 2>(M, B, ld, nc, c0, out, hot, lds_ld);
     switch (lpr) {
-      case 4: return spmm_launch<4, 1>(M, B, ld, out, hot, lds_ld);
-      case 8: return spmm_launch<8, 1>(M, B, ld, out, hot, lds_ld);
-      case 16: return spmm_launch<16, 1>(M, B, ld, out, hot, lds_ld);
-      case 32: return spmm_launch<32, 1>(M, B, ld, out, hot, lds_ld);
-      default: return spmm_launch<64, 1>(M, B, ld, out, hot, lds_ld);
+      case 4: return spmm_launch<4, 1>(M, B, ld, nc, c0, out, hot, lds_ld);
+      case 8: return spmm_launch<8, 1>(M, B, ld, nc, c0, out, hot, lds_ld);
+      case 16: return spmm_launch<16, 1>(M, B, ld, nc, c0, out, hot, lds_ld);
+      case 32: return spmm_launch<32, 1>(M, B, ld, nc, c0, out, hot, lds_ld);
+      default: return spmm_launch<64, 1>(M, B, ld, nc, c0, out, hot, lds_ld);
     }
+  }
+
+  // Padding (elements) of a factor row in the LDS images of the HOT and TILE modes.  A wave-level ds_read_b128 is
+  // served in four cycles of 16 lanes, and the 16 lanes of one cycle come from two different lane groups of the
+  // gather (MI355X LDS: {0-3,12-15,20-27}, ...), i.e. from two different rows when a row is covered by 16 lanes:
+  // the two rows' banks interleave without conflict only if both start on the same bank, so the row stride has to
+  // be a whole 256 bytes.  Round 1 padded every row by 16 bytes (the usual recipe against column-access conflicts),
+  // which is what made 37-39 % of the LDS cycles conflict cycles (profiles/r01_spmm_counters_tile_kernel.txt): 7.7
+  // cycles per instruction instead of 4 at ld = 64 fp32.  32 lanes per row and more: any stride is conflict-free once
+  // idle lanes no longer all read offset 0 (spmm.hpp, lbytes).  8 or 4 lanes per row: no stride avoids conflicts
+  // (7 of 4 cycles at best), the unpadded one is the least bad.
+  int lds_pad_for(int ld, int lpr) const {
+    if (tune.lds_pad >= 0) return (int)round_up(tune.lds_pad, VecOf<T>::N);
+    if (lpr == 16) return (int)(round_up((int64_t)ld * sizeof(T), 256) / sizeof(T)) - ld;
+    return 0;
   }
 
   template <int NT, int TR>
@@ -982,10 +1026,21 @@ class Engine : public ImplBase {
     for (size_t i = 0; i < fetch_count; ++i) out[i] = (double)hp[i];
     return 0;
   }
-  static double spectral_from_gram(const double* g, int ld) { return std::sqrt(std::max(0.0, nonneg_lambda_max(g, ld))); }
+  // A Gram with a non-finite entry (a factor went NaN / inf) must not look like a small norm: std::max(0.0, NaN) is
+  // 0.0 and the eigen-solver skips NaN diagonals, so test the entries before anything clamps.
+  static bool all_finite(const double* g, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+      if (!std::isfinite(g[i])) return false;
+    return true;
+  }
+  static double spectral_from_gram(const double* g, int ld) {
+    if (!all_finite(g, (size_t)ld * ld)) return NAN;
+    return std::sqrt(std::max(0.0, nonneg_lambda_max(g, ld)));
+  }
   static double fro_from_gram(const double* g, int ld) {
     double t = 0.0;
     for (int i = 0; i < ld; ++i) t += g[(size_t)i * ld + i];
+    if (!std::isfinite(t)) return NAN;
     return std::sqrt(std::max(0.0, t));
   }
 
@@ -1024,6 +1079,10 @@ class Engine : public ImplBase {
   struct LoopClock {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::chrono::steady_clock::time_point t0;
+    ~LoopClock() {  // error paths leave the loop without clock_stop
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
   };
   int clock_start(LoopClock& c) {
     E_HIP(hipEventCreate(&c.e0));
@@ -1045,6 +1104,7 @@ class Engine : public ImplBase {
     }
     (void)hipEventDestroy(c.e0);
     (void)hipEventDestroy(c.e1);
+    c.e0 = c.e1 = nullptr;
     return 0;
   }
 
@@ -1585,6 +1645,16 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  int k_s_confusion(int k, const void* S, int32_t* col, int32_t* row, void* val) override {
+    if (k <= 0 || k > 1024 || !S || !col || !row || !val) return fail(MNMF_EINVAL, "s_confusion: bad arguments (1 <= k <= 1024)");
+    E_HIP(hipSetDevice(ctx->device));
+    const int threads = (int)round_up(k, 64);
+    s_confusion_kernel<T><<<1, threads, (size_t)k * sizeof(T), st()>>>((const T*)S, k, k, col, row, (T*)val);
+    E_LAUNCH();
+    E_HIP(hipStreamSynchronize(st()));
+    return 0;
+  }
+
   int k_diff_norm(int64_t rows, int k, const void* A, const void* B, int kind, double* out) override {
     if (k <= 0 || rows < 0 || !out) return fail(MNMF_EINVAL, "diff_norm: bad arguments");
     E_HIP(hipSetDevice(ctx->device));
@@ -1602,184 +1672,11 @@ class Engine : public ImplBase {
 
 }  // namespace
 
-// =========================================================================== C-ABI
-extern "C" {
-
-const char* mnmf_version(void) { return "mnmf 0.1 (gfx950)"; }
-
-int mnmf_create(mnmf_ctx** out, int device, int dtype, void* hip_stream) {
-  if (!out || (dtype != MNMF_F32 && dtype != MNMF_F64)) return MNMF_EINVAL;
-  *out = nullptr;
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MNMF_EHIP;
-  if (hipSetDevice(device) != hipSuccess) return MNMF_EHIP;
-  mnmf_ctx* c = new mnmf_ctx();
-  c->device = device;
-  c->dtype = dtype;
-  c->stream = (hipStream_t)hip_stream;
-  if (dtype == MNMF_F32) c->impl = new Engine<float>(c); else c->impl = new Engine<double>(c);
-  *out = c;
-  return MNMF_OK;
-}
-
-void mnmf_destroy(mnmf_ctx* ctx) {
-  if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
-  delete ctx->impl;
-  delete ctx;
-}
-
-const char* mnmf_last_error(const mnmf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-
-int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ranks) {
-  if (!ctx) return MNMF_EINVAL;
-  ctx->ar = fn;
-  ctx->ar_user = user;
-  ctx->n_ranks = n_ranks > 0 ? n_ranks : 1;
-  return ctx->impl->hook_changed();
-}
-
-int mnmf_set_matrix(mnmf_ctx* ctx, int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
-                    const void* vals, int on_device) {
-  if (!ctx) return MNMF_EINVAL;
-  return ctx->impl->set_matrix(m, V, nnz, rowptr, colidx, vals, on_device);
-}
-
-int mnmf_run_nmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
-  if (!ctx || !W || !H) return MNMF_EINVAL;
-  return ctx->impl->run_nmf(k, W, H, opts, stats);
-}
-int mnmf_run_pnmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
-  if (!ctx || !W || !H) return MNMF_EINVAL;
-  return ctx->impl->run_pnmf(k, W, H, opts, stats);
-}
-int mnmf_run_nmtf(mnmf_ctx* ctx, int k, void* W, void* S, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
-  if (!ctx || !W || !S || !H) return MNMF_EINVAL;
-  return ctx->impl->run_nmtf(k, W, S, H, opts, stats);
-}
-int mnmf_spmm(mnmf_ctx* ctx, int transpose, int k, const void* B, void* out) {
-  if (!ctx || !B || !out) return MNMF_EINVAL;
-  return ctx->impl->k_spmm(transpose, k, B, out);
-}
-int mnmf_gram(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, void* out) {
-  if (!ctx || !A || !out) return MNMF_EINVAL;
-  return ctx->impl->k_gram(rows, k, A, B, out);
-}
-int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* num, const void* G, const void* G2,
-                double eps, int sqrt_mode, void* out) {
-  if (!ctx || !A || !num || !G || !out) return MNMF_EINVAL;
-  return ctx->impl->k_update(rows, k, A, num, G, G2, eps, sqrt_mode, out);
-}
-int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind, double* out) {
-  if (!ctx || !A || !B) return MNMF_EINVAL;
-  return ctx->impl->k_diff_norm(rows, k, A, B, norm_kind, out);
-}
-
-int mnmf_topk(mnmf_ctx* ctx, int64_t rows, int64_t cols, const void* A, int by_column, int n, int32_t* idx_out,
-              void* val_out) {
-  if (!ctx) return MNMF_EINVAL;
-  return ctx->impl->k_topk(rows, cols, A, by_column, n, idx_out, val_out);
-}
-
-int mnmf_memcpy_d2d(mnmf_ctx* ctx, void* dst, const void* src, int64_t bytes) {
-  if (!ctx || !dst || !src || bytes < 0) return MNMF_EINVAL;
-  if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
-    ctx->fail(MNMF_EHIP, "mnmf_memcpy_d2d failed");
-    return MNMF_EHIP;
-  }
-  return MNMF_OK;
-}
-
-static void export_segments(const HostSegments& s, mnmf_segments* out) {
-  auto dup64 = [](const std::vector<int64_t>& v) {
-    int64_t* p = (int64_t*)std::malloc(std::max<size_t>(v.size(), 1) * 8);
-    std::memcpy(p, v.data(), v.size() * 8);
-    return p;
-  };
-  auto dup32 = [](const std::vector<int32_t>& v) {
-    int32_t* p = (int32_t*)std::malloc(std::max<size_t>(v.size(), 1) * 4);
-    std::memcpy(p, v.data(), v.size() * 4);
-    return p;
-  };
-  out->n_seg = s.n_seg();
-  out->seg_start = dup64(s.seg_start);
-  out->seg_len = dup32(s.seg_len);
-  out->seg_info = dup32(s.seg_info);
-  out->n_dest = (int64_t)s.dest.size();
-  out->dest = dup32(s.dest);
-  out->piece_end = dup64(s.piece_end);
-  out->n_empty = (int64_t)s.empty_rows.size();
-  out->empty_rows = dup32(s.empty_rows);
-  out->n_fix = (int64_t)s.fix_row.size();
-  out->fix_row = dup32(s.fix_row);
-  out->fix_first = dup32(s.fix_first);
-  out->fix_count = dup32(s.fix_count);
-  out->n_carry = s.n_carry;
-}
-
-int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, int64_t sub_piece, mnmf_segments* out) {
-  if (!rowptr || !out || rows < 0) return MNMF_EINVAL;
-  HostPieces pc;
-  pieces_from_rowptr(rowptr, rows, pc);
-  HostSegments s;
-  build_segments_host(pc, rows, seg_nnz, sub_piece, s);
-  export_segments(s, out);
-  return MNMF_OK;
-}
-
-int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
-                               int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece, int xcd_group,
-                               mnmf_segments* out) {
-  if (!piece_start || !out || rows < 0 || n_pieces < 0 || (n_pieces > 0 && !piece_row)) return MNMF_EINVAL;
-  HostPieces pc;
-  pc.start.assign(piece_start, piece_start + n_pieces + 1);
-  pc.row.assign(piece_row, piece_row + n_pieces);
-  if (piece_block) pc.block.assign(piece_block, piece_block + n_pieces);
-  for (int64_t i = 0; i < n_pieces; ++i)
-    if (pc.row[i] < 0 || pc.row[i] >= rows || pc.start[i + 1] <= pc.start[i]) return MNMF_EINVAL;
-  HostSegments s;
-  build_segments_host(pc, rows, seg_nnz, sub_piece, s, piece_block ? xcd_group : 0);
-  export_segments(s, out);
-  return MNMF_OK;
-}
-
-int mnmf_build_segments_tiles(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_tile,
-                              int64_t n_pieces, int64_t rows, int64_t n_tiles, int64_t seg_nnz, int64_t sub_piece,
-                              mnmf_segments* out, int32_t* tile_first) {
-  if (!piece_start || !out || !tile_first || rows < 0 || n_pieces < 0 || n_tiles < 0 || (n_pieces > 0 && (!piece_row || !piece_tile)))
-    return MNMF_EINVAL;
-  HostPieces pc;
-  pc.start.assign(piece_start, piece_start + n_pieces + 1);
-  pc.row.assign(piece_row, piece_row + n_pieces);
-  pc.block.assign(piece_tile, piece_tile + n_pieces);
-  for (int64_t i = 0; i < n_pieces; ++i)
-    if (pc.row[i] < 0 || pc.row[i] >= rows || pc.start[i + 1] <= pc.start[i] || pc.block[i] < 0 || pc.block[i] >= n_tiles ||
-        (i > 0 && pc.block[i] < pc.block[i - 1]))
-      return MNMF_EINVAL;
-  HostSegments s;
-  std::vector<int32_t> tf;
-  if (seg_nnz <= 0) build_tile_segments_host(pc, rows, n_tiles, (int)std::max<int64_t>(1, -seg_nnz), sub_piece, s, tf);
-  else build_segments_host(pc, rows, seg_nnz, sub_piece, s, 0, &tf, n_tiles);
-  tf.resize((size_t)n_tiles + 1, (int32_t)s.n_seg());
-  std::memcpy(tile_first, tf.data(), ((size_t)n_tiles + 1) * sizeof(int32_t));
-  export_segments(s, out);
-  return MNMF_OK;
-}
-
-void mnmf_free_segments(mnmf_segments* s) {
-  if (!s) return;
-  std::free(s->seg_start);
-  std::free(s->seg_len);
-  std::free(s->seg_info);
-  std::free(s->dest);
-  std::free(s->piece_end);
-  std::free(s->empty_rows);
-  std::free(s->fix_row);
-  std::free(s->fix_first);
-  std::free(s->fix_count);
-  std::memset(s, 0, sizeof(*s));
-}
-
-double mnmf_sym_lambda_max(const double* a, int n) { return a ? sym_lambda_max_jacobi(a, n) : 0.0; }
-
-}  // extern "C"
+#ifndef MNMF_ENGINE_DTYPE
+#error "compile engine.hip with -DMNMF_ENGINE_DTYPE=32 or 64"
+#endif
+#if MNMF_ENGINE_DTYPE == 32
+ImplBase* mnmf_make_engine_f32(mnmf_ctx* c) { return new Engine<float>(c); }
+#else
+ImplBase* mnmf_make_engine_f64(mnmf_ctx* c) { return new Engine<double>(c); }
+#endif

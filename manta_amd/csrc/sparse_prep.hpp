@@ -219,18 +219,18 @@ inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_
 }
 
 // ---------------------------------------------------------------- device preprocessing kernels
-__global__ void set_flags_at_kernel(const int64_t* __restrict__ pos, int64_t n, uint32_t* cols) {
+static __global__ void set_flags_at_kernel(const int64_t* __restrict__ pos, int64_t n, uint32_t* cols) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) cols[pos[i]] |= kEndFlag;
 }
 
-__global__ void clear_flags_kernel(uint32_t* cols, int64_t n) {
+static __global__ void clear_flags_kernel(uint32_t* cols, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) cols[i] &= ~kEndFlag;
 }
 
 // rowid[p] = row that owns nnz p (binary search over the row pointer); iota[p] = p.
-__global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int64_t rows, int64_t nnz,
+static __global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int64_t rows, int64_t nnz,
                                      uint32_t* __restrict__ rowid, uint32_t* __restrict__ iota) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nnz) return;
@@ -247,7 +247,7 @@ __global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int64_t row
 // renumbering) go to the TILE stream: key = tile * n_hot + word with tile = document / tile_rows, all below hot_span.
 // The others: hot_span + (document block, word); vocabulary rows with at most `long_df` nnz are not blocked
 // (pseudo-block n_blocks), so they stay one piece.
-__global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rowid,
+static __global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rowid,
                                      const int32_t* __restrict__ df, int64_t nnz, int64_t V, int block_shift,
                                      uint32_t n_blocks, int32_t long_df, uint32_t n_hot, uint32_t tile_rows,
                                      uint32_t hot_span, uint32_t* __restrict__ key) {
@@ -263,20 +263,20 @@ __global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, const ui
 }
 
 // flag[p] = 1 where a new piece starts (key differs from the previous nnz).
-__global__ void piece_flag_kernel(const uint32_t* __restrict__ key, int64_t nnz, uint8_t* __restrict__ flag) {
+static __global__ void piece_flag_kernel(const uint32_t* __restrict__ key, int64_t nnz, uint8_t* __restrict__ flag) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nnz) return;
   flag[p] = (p == 0 || key[p] != key[p - 1]) ? 1 : 0;
 }
 
 // order[i] = old id of the row with new id i  ->  newid[old] = i
-__global__ void invert_perm_kernel(const uint32_t* __restrict__ order, int64_t n, int32_t* __restrict__ newid) {
+static __global__ void invert_perm_kernel(const uint32_t* __restrict__ order, int64_t n, int32_t* __restrict__ newid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) newid[order[i]] = (int32_t)i;
 }
 
 // cols[p] = map[cols[p]]  (end flags must be clear)
-__global__ void remap_cols_kernel(uint32_t* cols, int64_t nnz, const int32_t* __restrict__ map) {
+static __global__ void remap_cols_kernel(uint32_t* cols, int64_t nnz, const int32_t* __restrict__ map) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < nnz) cols[p] = (uint32_t)map[cols[p]];
 }
@@ -290,7 +290,7 @@ __global__ void df_to_key_kernel(const int32_t* __restrict__ df, int64_t n, T* _
   }
 }
 
-__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t n,
+static __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t n,
                                   uint32_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = src[idx[i]];

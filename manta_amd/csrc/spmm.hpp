@@ -42,7 +42,8 @@ struct SpmmArgs {
   const int32_t* dest;       // per piece: >= 0 output row, < 0 ~carry slot
   int64_t n_dest;
   const T* B;                // gather table, tab_rows x ld
-  int ld;
+  int ld;                    // row stride of B, out and carry (elements)
+  int nc;                    // columns handled by this launch (<= ld; < ld when a very wide factor is done in column chunks)
   T* out;
   T* carry;
   int hot_rows;              // HOT: first rows of B staged in LDS
@@ -104,12 +105,17 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
   const int gi = lane / LPR, li = lane % LPR;
   const int gbase = gi * LPR;
   bool colok[VPL];
-  uint32_t cbytes[VPL];  // byte offset of this lane's vector in a row (clamped to 0 for lanes beyond ld)
+  uint32_t cbytes[VPL];  // byte offset of this lane's vector in a row (clamped to 0 for lanes beyond the columns)
+  uint32_t lbytes[VPL];  // the same for LDS reads, NOT clamped: idle lanes that all read offset 0 of their row put a
+                         // second address on banks other lanes of the same ds_read_b128 lane group use (6 LDS cycles
+                         // per instruction instead of 4 at ld = 112); reading on into the next row is conflict-free
+                         // and harmless (the host sizes the LDS image with one vector row of slack)
 #pragma unroll
   for (int w = 0; w < VPL; ++w) {
     const int coff = (w * LPR + li) * VEC;
-    colok[w] = coff < ld;
+    colok[w] = coff < a.nc;
     cbytes[w] = colok[w] ? (uint32_t)coff * (uint32_t)sizeof(T) : 0u;
+    lbytes[w] = (uint32_t)coff * (uint32_t)sizeof(T);
   }
   const uint32_t rowbytes = (uint32_t)ld * (uint32_t)sizeof(T);
   const uint32_t lds_rowbytes = (uint32_t)a.lds_ld * (uint32_t)sizeof(T);
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
             const uint32_t lrow = __umul24(c[u], lds_rowbytes);  // u24: the flag bit drops out
 #pragma unroll
             for (int w = 0; w < VPL; ++w) {
-              const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + cbytes[w]);
+              const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + lbytes[w]);
               __builtin_memcpy(&b[u][w], &l, sizeof(VT));
             }
           } else if (HOT) {
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
             const uint32_t lrow = __umul24(hot ? col : 0u, lds_rowbytes);
 #pragma unroll
             for (int w = 0; w < VPL; ++w) {
-              const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + cbytes[w]);
+              const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + lbytes[w]);
               U4 g;
               if (!hot) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(col, rowbytes) + cbytes[w], 0, 0);
               const U4 sel = hot ? l : g;
@@ -298,7 +304,7 @@ template <typename T, int LPR, int VPL>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t* __restrict__ fix_row,
                                                          const int32_t* __restrict__ fix_first,
                                                          const int32_t* __restrict__ fix_count, int64_t n_fix,
-                                                         const T* __restrict__ carry, int ld,
+                                                         const T* __restrict__ carry, int ld, int nc,
                                                          T* __restrict__ out) {
   constexpr int VEC = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t* __restri
 #pragma unroll
     for (int w = 0; w < VPL; ++w) {
       const int co = (w * LPR + li) * VEC;
-      if (co < ld) {
+      if (co < nc) {
         const VT t = *reinterpret_cast<const VT*>(cp + co);
 #pragma unroll
         for (int x = 0; x < VEC; ++x) acc[w][x] += t.v[x];
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t* __restri
 #pragma unroll
     for (int w = 0; w < VPL; ++w) {
       const int co = (w * LPR + li) * VEC;
-      if (co < ld) {
+      if (co < nc) {
         VT o;
 #pragma unroll
         for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
@@ -354,7 +360,7 @@ template <typename T, int LPR, int VPL, int NW>
 __global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t* __restrict__ fix_row,
                                                               const int32_t* __restrict__ fix_first,
                                                               const int32_t* __restrict__ fix_count,
-                                                              const T* __restrict__ carry, int ld,
+                                                              const T* __restrict__ carry, int ld, int nc,
                                                               T* __restrict__ out) {
   constexpr int VEC = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t*
 #pragma unroll
     for (int w = 0; w < VPL; ++w) {
       const int co = (w * LPR + li) * VEC;
-      if (co < ld) {
+      if (co < nc) {
         const VT t = *reinterpret_cast<const VT*>(cp + co);
 #pragma unroll
         for (int x = 0; x < VEC; ++x) acc[w][x] += t.v[x];
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t*
 #pragma unroll
     for (int w = 0; w < VPL; ++w) {
       const int co = (w * LPR + li) * VEC;
-      if (co < ld) {
+      if (co < nc) {
         VT o;
 #pragma unroll
         for (int x = 0; x < VEC; ++x) {

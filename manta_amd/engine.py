@@ -75,6 +75,7 @@ class Engine:
         self.m = self.V = self.nnz = 0
         self._hook = None      # keep the ctypes callback alive
         self._stage = None
+        self._resident_key = None   # identity of the scipy matrix run_nmf last uploaded (manta_amd.nmf)
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -111,6 +112,7 @@ class Engine:
     def set_matrix(self, X=None, *, rowptr=None, colidx=None, vals=None, shape=None):
         """``X``: a scipy sparse matrix (host), or give device/host tensors ``rowptr`` (int64), ``colidx``
         (int32), ``vals`` and ``shape``.  The engine copies and keeps X and X^T resident."""
+        self._resident_key = None   # whoever replaces the matrix invalidates run_nmf's residency marker
         if X is not None:
             X = X.tocsr()
             X.sort_indices()
@@ -129,6 +131,10 @@ class Engine:
                                               vals.data_ptr(), 1))
         self.m, self.V, self.nnz = m, V, nnz
         self._vals_minmax = (float(vals.min()), float(vals.max())) if nnz else (0.0, 0.0)
+
+    def row_stride(self, k):
+        """Elements per factor row in the engine's padded layout (mnmf_row_stride)."""
+        return int(self._lib.mnmf_row_stride(self._h, int(k)))
 
     def value_range(self):
         """(X.min(), X.max()) as scipy defines them for a sparse matrix: implicit zeros count unless X is full."""
@@ -264,6 +270,26 @@ class Engine:
             words = words[rows]
         return words, docs
 
+    def s_matrix_confusion(self, S, console=None):
+        """The NMTF topic-relationship summary of ``s_matrix_confusion`` (nmtf/nmtf.py:62-80) computed where S lives:
+        per column of S its strongest row (``np.argmax``) and that strength, strongest coupling first.  Returns
+        ``(columns, rows, strengths)`` as numpy arrays in rank order; with ``console`` (anything with the reference's
+        ``print_debug(msg, tag=...)``) it also emits the reference's log lines -- which number the couplings by RANK,
+        not by column ("Topic {rank} has connection with Topic {row}")."""
+        S = self._dev(S)
+        k = S.shape[0]
+        if S.shape != (k, k):
+            raise ValueError("S must be square")
+        col = torch.empty(k, dtype=torch.int32, device=self.device)
+        row = torch.empty(k, dtype=torch.int32, device=self.device)
+        val = torch.empty(k, dtype=self.tdtype, device=self.device)
+        self._check(self._lib.mnmf_s_confusion(self._h, k, S.data_ptr(), col.data_ptr(), row.data_ptr(), val.data_ptr()))
+        cols, rows, vals = col.cpu().numpy(), row.cpu().numpy(), val.cpu().double().numpy()
+        if console is not None:
+            for line in confusion_lines(rows, vals):
+                console.print_debug(line, tag="S-MATRIX")
+        return cols, rows, vals
+
     def relevance_rankings(self, W, H, S=None, lambda_val=0.6, top_n=15):
         """LDAvis-style relevance ranking of the coherence step evaluated where the factors live
         (gensim_coherence.py:40-140): relevance = lambda * log p(word|topic) + (1 - lambda) * log lift, words with topic
@@ -296,6 +322,11 @@ class Engine:
         self._check(self._lib.mnmf_diff_norm(self._h, A.shape[0], A.shape[1], A.data_ptr(), B.data_ptr(),
                                              0 if kind == "spectral" else 1, C.byref(out)))
         return out.value
+
+
+def confusion_lines(rows, strengths):
+    """The log lines of the reference's s_matrix_confusion (nmtf.py:77-78) for couplings in rank order."""
+    return [f"Topic {r} has connection with Topic {rows[r]}, strength: {strengths[r]}" for r in range(len(rows))]
 
 
 def build_segments(rowptr=None, seg_nnz=64, sub_piece=512, *, piece_start=None, piece_row=None, piece_block=None,

@@ -28,12 +28,27 @@ def find_max_rank(sparse_matrix) -> int:
     return int(sparse_matrix.count_nonzero() / (m + n))
 
 
+def _device_index(device) -> int:
+    """None, 0, "cuda:0" and torch.device("cuda", 0) are the same GPU: one cached engine (and one resident copy of
+    X and X^T) per GPU and dtype, whatever form the caller names it in."""
+    import torch
+
+    if device is None:
+        return torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.index is not None:
+        return d.index
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
 def _engine(dtype, device):
     from .engine import Engine
 
-    key = (dtype, device)
+    key = (dtype, _device_index(device))
     if key not in _ENGINES:
-        _ENGINES[key] = Engine(device=device, dtype=dtype)
+        _ENGINES[key] = Engine(device=key[1], dtype=dtype)
     return _ENGINES[key]
 
 
@@ -53,7 +68,7 @@ def _matrix_key(mat):
 def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initialization_nndsvd, norm_thresh=0.001,
             zero_threshold=0.00001, nmf_method: str = "nmf", console=None, *, dtype: Optional[str] = None,
             device=None, max_iter: Optional[int] = None, fixed_iters: Optional[int] = None, check_every: int = 1,
-            W0=None, H0=None, S0=None, stats_out: Optional[dict] = None) -> dict:
+            W0=None, H0=None, S0=None, seed: int = 0, stats_out: Optional[dict] = None) -> dict:
     """Factorise ``sparse_matrix`` (docs x vocab) into ``{"W": (m,k), "H": (k,V)[, "S": (k,k)]}``,
     float64 C-contiguous ndarrays, exactly as the reference does.
 
@@ -64,11 +79,14 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
 
     Keyword-only extras (not in the reference): ``dtype`` "fp64" (default; env MANTA_AMD_DTYPE) or
     "fp32"; ``device``; ``max_iter`` / ``fixed_iters`` / ``check_every``; explicit ``W0``/``H0``/``S0``;
+    for nmtf either all three of ``W0``/``S0``/``H0`` or none (``ValueError`` otherwise);
     ``init="device"`` computes the NNDSVD start on the GPU (``manta_amd.init_device``: block Lanczos over the
     engine's SpMM kernels instead of ARPACK on the host; agrees with the host path to ~1e-6, not bit for bit; for
     nmtf it is the legacy double NNDSVD, nmtf_init.py:19-41); ``init="device_random"`` draws the uniform start of
-    ``nmf_initialization_random`` on the GPU (same distribution, its own seeded stream);
-    ``stats_out`` dict receives iteration count, norms and timings.
+    ``nmf_initialization_random`` on the GPU (same distribution, its own stream seeded with ``seed`` -- unlike numpy's
+    global generator, the same seed gives the same start on every call);
+    ``stats_out`` dict receives iteration count, norms and timings (nmtf: also ``s_confusion``, the strongest coupling
+    per S column in rank order -- what the reference's ``s_matrix_confusion`` logs, nmtf.py:62-80, 214).
     The engine keeps the last matrix resident: a second call with the same matrix object (unchanged content), as in
     a topic-count sweep, skips the upload and the stream preprocessing (``stats_out["matrix_resident"]``).
     """
@@ -78,9 +96,14 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     if device_init and init not in ("device", "device_random"):
         raise ValueError("init must be a callable (csc, rank) -> (W0, H0) or one of the strings 'device', 'device_random'")
     have_init = W0 is not None and H0 is not None
+    if nmf_method == "nmtf" and (W0 is not None or H0 is not None) and (S0 is None or W0 is None or H0 is None):
+        raise ValueError("nmtf: explicit starts need all of W0, S0 and H0 (the reference derives the three together, "
+                         "nmtf.py:224); pass none of them to get its legacy double NNDSVD")
     key = _matrix_key(sparse_matrix)
+    # X (and its streams) already on the GPU?  The marker lives on the engine and Engine.set_matrix clears it, so
+    # another user of the cached engine (tfidf, a direct set_matrix) cannot leave a stale one behind.
     resident = key is not None and \
-        getattr(_ENGINES.get((dtype, device)), "_resident_key", None) == key   # X (and its streams) already on the GPU
+        getattr(_ENGINES.get((dtype, _device_index(device))), "_resident_key", None) == key
     host_init = (not device_init and not have_init) or \
         (nmf_method == "nmtf" and not device_init and (S0 is None or not have_init))
     # the reference converts to CSC first (:168) and to CSR for the solvers (:116); the CSC copy is only made here when
@@ -101,14 +124,13 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
         csr = (csc if csc is not None else sparse_matrix).tocsr()          # :116
     eng = _engine(dtype, device)
     if not resident:
-        eng._resident_key = None
-        eng.set_matrix(csr)
+        eng.set_matrix(csr)              # clears the marker
         eng._resident_key = key
     s_dev = None
     if device_init and not (have_init and (nmf_method != "nmtf" or S0 is not None)):
         from . import init_device as idv                                   # starts computed on the matrix already resident
         if init == "device_random":
-            w, s_dev, h = idv.random_device(eng, topic_count, with_s=True)
+            w, s_dev, h = idv.random_device(eng, topic_count, seed=seed, with_s=True)
         elif nmf_method == "nmtf":
             w, s_dev, h = idv.nmtf_nndsvd_legacy_device(eng, topic_count)  # nmtf.py:224
         else:
@@ -133,6 +155,8 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
             s = S0
         W, S, H, st = eng.run_nmtf(w, s, h, norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)  # :127
         out = {"W": W, "S": S, "H": H}
+        if stats_out is not None:                                          # the summary the reference logs, nmtf.py:214
+            stats_out["s_confusion"] = eng.s_matrix_confusion(S)
     out = {k_: np.ascontiguousarray(eng._host(v)) for k_, v in out.items()}
     if any(v is None for v in out.values()):
         raise RuntimeError(f"NMF computation failed for method: {nmf_method}")  # :133

@@ -280,6 +280,20 @@ def topic_rankings(H, W, S=None, top_n=15):
     return np.array(words), np.array(docs)
 
 
+def s_matrix_confusion(S):
+    """The NMTF topic-relationship summary the reference logs after every nmtf run (nmtf/nmtf.py:62-80): per column
+    of S its argmax row and that value (:67-71), columns ordered by value descending (:73-75).  Returns
+    (columns, rows, values, log lines); the lines are the reference's own (:77-78), which number the couplings by
+    rank.  Pinned to tests/golden/sconf.npz (lines recorded from the unmodified reference function)."""
+    S = np.asarray(S)
+    rows = np.array([int(np.argmax(S[:, i])) for i in range(S.shape[1])])
+    vals = np.array([S[rows[i], i] for i in range(S.shape[1])])
+    order = np.argsort(vals)[::-1]
+    cols, rows, vals = order, rows[order], vals[order]
+    lines = [f"Topic {r} has connection with Topic {rows[r]}, strength: {vals[r]}" for r in range(len(rows))]
+    return cols, rows, vals, lines
+
+
 def relevance_rankings(H, W, S=None, lambda_val=0.6, top_n=15):
     """LDAvis-style relevance ranking used by the coherence step, before any vocabulary string filtering
     (manta/utils/analysis/gensim_coherence.py:40-103 and :106-140): per topic the word ids in descending relevance

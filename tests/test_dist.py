@@ -51,3 +51,22 @@ def test_sharded_schedule_gloo_cpu(method):
 @pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
 def test_sharded_engine_two_ranks_one_gpu(method, dtype):
     launch(["engine", method, dtype], 29631 + ["nmf", "pnmf", "nmtf"].index(method) + (3 if dtype == "fp32" else 0))
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts --gpus 1) must start its ranks as a
+    child torch.distributed.run and print one JSON line with n_gpus = 2.  Two ranks share the one GPU here, so the
+    exchange goes through gloo; the command line is otherwise the driver's."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "c1", "--backend", "gloo", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "doc-shard x2"

@@ -154,6 +154,7 @@ def _inits(m, V, k, xmax, dev, seed=42):
     ("nmf", 1_000_000, 100_000, 0.001, 50, 2),      # configs[1]
     ("pnmf", 1_000_000, 100_000, 0.001, 100, 2),    # configs[2]
     ("nmtf", 2_000_000, 200_000, 0.0005, 20, 2),    # configs[3]
+    ("nmf", 2_500_000, 500_000, 0.0002, 200, 2),    # one rank's share of configs[4] (20M x 500k, k = 200, 8 ranks)
 ])
 def test_solver_iterations_against_torch_float64_full_size(method, m, V, density, k, iters):
     import torch
@@ -199,3 +200,38 @@ def test_solver_iterations_against_torch_float64_full_size(method, m, V, density
             assert st.iters == iters
         finally:
             eng.close()
+
+
+def test_config4_shard_products_adjointness_reproducibility():
+    """One rank's share of configs[4] (2.5M docs x 500k vocab, 2.5e8 nnz, k = 200; 832-byte factor rows, two vectors
+    per lane, 2 GB gather tables): X.B and X^T.A against float64 references built from the same device arrays,
+    adjointness, and bit-reproducibility of both products (fp32, the dtype the config is quoted in)."""
+    import torch
+    from manta_amd.engine import Engine
+    from manta_amd.synth import zipf_tfidf_csr
+
+    m, V, k = 2_500_000, 500_000, 200
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = zipf_tfidf_csr(m, V, 0.0002, seed=1234, device=dev, dtype=torch.float64)
+    x_times, xt_times = _torch_ops(rowptr, col, val, m, V, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    B = torch.rand((V, k), generator=g, device=dev, dtype=torch.float32)
+    A = torch.rand((m, k), generator=g, device=dev, dtype=torch.float32)
+    eng = Engine(dtype="fp32")
+    try:
+        eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(m, V))
+        XB = eng.spmm(B)
+        assert _rel(XB, x_times(B.double())) <= 2e-6
+        XtA = eng.spmm(A, transpose=True)
+        want = torch.zeros((V, k), device=dev, dtype=torch.float64)   # X^T.A in column halves: bounded temporaries
+        for c0 in range(0, k, 50):
+            want[:, c0:c0 + 50] = xt_times(A[:, c0:c0 + 50].double())
+        assert _rel(XtA, want) <= 2e-6
+        del want
+        lhs = float((XB.double() * A.double()).sum())
+        rhs = float((B.double() * XtA.double()).sum())
+        assert abs(lhs - rhs) <= 2e-5 * abs(rhs)
+        assert torch.equal(eng.spmm(A, transpose=True), XtA) and torch.equal(eng.spmm(B), XB)
+    finally:
+        eng.close()

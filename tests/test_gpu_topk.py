@@ -90,3 +90,37 @@ def test_relevance_rankings_match_oracle(engines, golden, method, dtype):
     idx, val = engines[dtype].relevance_rankings(W, H2, None if S is None else S, top_n=10)
     idx_ref, _ = oc.relevance_rankings(H2, W, S, top_n=10)
     assert np.array_equal(idx.cpu().numpy() >= 0, idx_ref >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_s_matrix_confusion_matches_reference_lines(dtype):
+    """Engine.s_matrix_confusion (mnmf_s_confusion) against the lines recorded from the reference's s_matrix_confusion
+    (tests/golden/sconf.npz, nmtf/nmtf.py:62-80).  fp64: the very strings; fp32: the same couplings in the same order."""
+    import os
+    from manta_amd.engine import Engine, confusion_lines
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sconf.npz"), allow_pickle=False)
+    eng = Engine(device=0, dtype=dtype)
+
+    class Rec:
+        def __init__(self):
+            self.lines = []
+
+        def print_debug(self, msg, tag=None):
+            assert tag == "S-MATRIX"
+            self.lines.append(msg)
+
+    for name in z["names"]:
+        S = z[f"S_{name}"]
+        rec = Rec()
+        cols, rows, vals = eng.s_matrix_confusion(S, console=rec)
+        o_cols, o_rows, o_vals, o_lines = oc.s_matrix_confusion(S)
+        assert np.array_equal(cols, o_cols) and np.array_equal(rows, o_rows)
+        if dtype == "fp64":
+            assert np.array_equal(vals, o_vals)
+            assert rec.lines == z[f"lines_{name}"].tolist() == o_lines
+        else:
+            assert np.allclose(vals, o_vals, rtol=1e-6)
+            assert len(rec.lines) == S.shape[1] and rec.lines == confusion_lines(rows, vals)
+    eng.close()

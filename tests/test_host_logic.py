@@ -264,3 +264,90 @@ def test_init_device_dense_helpers_on_cpu():
     Qd = _orthonormal_columns(D)
     assert Qd.shape[1] == 4 and torch.allclose(Qd.t() @ Qd, torch.eye(4, dtype=torch.float64), atol=1e-10)
     assert _orthonormal_columns(D, drop=False) is None
+
+
+def test_product_nndsvd_matches_reference_fixture(golden):
+    """manta_amd.init (the default `init` of the product's run_nmf) against W0/H0 and the NMTF legacy starts that the
+    unmodified reference produced under the fixture's numpy seed (nmf_initialization.py:38-83, nmtf_init.py:19-41):
+    bit for bit, signed zeros aside (`==` does not tell them apart and the reference's own clean-up removes them)."""
+    from manta_amd import init as pi
+
+    g = golden("converged_D_600x500_k6_nmtf")
+    np.random.seed(int(g["seed"]))
+    w, h = pi.nmf_initialization_nndsvd(g["X"].tocsc(), int(g["k"]))
+    assert w.flags.c_contiguous and h.flags.c_contiguous and w.dtype == np.float64
+    assert np.array_equal(w, g["W0"]) and np.array_equal(h, g["H0"])
+    wt, st, ht = pi.nmtf_initialization_nndsvd_legacy(g["X"].tocsr(), int(g["k"]))
+    assert np.array_equal(wt, g["Wt0"]) and np.array_equal(st, g["St0"]) and np.array_equal(ht, g["Ht0"])
+    assert not np.signbit(w[w == 0]).any() and not np.signbit(h[h == 0]).any()
+    for name in ("nmf", "pnmf"):   # the same start is what the other two converged fixtures recorded
+        g2 = golden(f"converged_D_600x500_k6_{name}")
+        assert np.array_equal(w, g2["W0"]) and np.array_equal(h, g2["H0"])
+
+
+def test_install_rebinds_run_nmf_where_manta_binds_it():
+    """install() must replace `run_nmf` on every module that binds the name at import time
+    (modeling_pipeline.py:10, optimization_pipeline.py:16, the nmf package and its orchestrator) and, with tfidf=True,
+    the TF-IDF builders where they are bound (english_entry.py:10, turkish_entry.py:4).  MANTA itself is not installed
+    here: stand-in modules with the same names and the same attributes are registered for the duration of the test."""
+    import sys
+    import types
+
+    import manta_amd
+    from manta_amd import tfidf as t
+
+    sentinel = object()
+    with_run = ["manta._functions.nmf.nmf_orchestrator", "manta._functions.nmf", "manta._functions",
+                "manta.pipeline.modeling_pipeline", "manta.pipeline.optimization_pipeline"]
+    with_tfidf = ["manta._functions.tfidf", "manta._functions", "manta._functions.english.english_entry",
+                  "manta._functions.turkish.turkish_entry"]
+    others = ["manta", "manta.pipeline", "manta._functions.english", "manta._functions.turkish", "manta.pipeline.text_pipeline"]
+    saved = {n: sys.modules.get(n) for n in set(with_run + with_tfidf + others)}
+    try:
+        for n in saved:
+            mod = types.ModuleType(n)
+            mod.__path__ = []
+            sys.modules[n] = mod
+        for n in with_run:
+            sys.modules[n].run_nmf = sentinel
+        for n in with_tfidf:
+            sys.modules[n].tf_idf_english = sentinel
+        sys.modules["manta._functions.turkish.turkish_entry"].tf_idf_turkish = sentinel
+        sys.modules["manta.pipeline.text_pipeline"].unrelated = sentinel
+        patched = manta_amd.install()
+        assert sorted(patched) == sorted(with_run)
+        for n in with_run:
+            assert sys.modules[n].run_nmf is manta_amd.run_nmf
+        assert sys.modules["manta._functions.tfidf"].tf_idf_english is sentinel      # not asked for
+        assert not hasattr(sys.modules["manta.pipeline"], "run_nmf")                   # nothing is added where nothing was bound
+        patched = manta_amd.install(tfidf=True)
+        for n in with_tfidf:
+            assert sys.modules[n].tf_idf_english is t.tf_idf_english and f"{n}.tf_idf_english" in patched
+        assert sys.modules["manta._functions.turkish.turkish_entry"].tf_idf_turkish is t.tf_idf_turkish
+        assert not hasattr(sys.modules["manta._functions.tfidf"], "tf_idf_turkish")
+        assert sys.modules["manta.pipeline.text_pipeline"].unrelated is sentinel
+    finally:
+        for n, mod in saved.items():
+            if mod is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = mod
+
+
+def test_nmtf_needs_all_three_explicit_starts():
+    """W0/H0 without S0 used to be dropped silently for nmtf; now it is an error before anything touches the GPU."""
+    import manta_amd
+
+    X = sp.random(30, 20, density=0.3, format="csr", random_state=0)
+    W0, H0 = np.ones((30, 3)), np.ones((3, 20))
+    with pytest.raises(ValueError, match="W0, S0 and H0"):
+        manta_amd.run_nmf(3, X, nmf_method="nmtf", W0=W0, H0=H0)
+
+
+def test_cached_engine_key_is_the_gpu_not_the_spelling():
+    from manta_amd import nmf
+
+    import torch
+    assert nmf._device_index(0) == nmf._device_index("cuda:0") == nmf._device_index(torch.device("cuda", 0)) == 0
+    assert nmf._device_index(torch.device("cuda", 3)) == 3
+    assert isinstance(nmf._device_index(None), int)

@@ -141,3 +141,16 @@ def test_tfidf_oracle_reduceat_errors():
         to.tf_idf_english(3, 5, [[0, 1], [2], [3]])
     with pytest.raises(IndexError):                                   # empty last document
         to.tf_idf_english(3, 4, [[0, 1], [2, 3], []])
+
+
+def test_s_matrix_confusion_oracle_reproduces_reference_lines():
+    """oracle.s_matrix_confusion against the debug lines the unmodified reference function emitted
+    (oracle/make_golden_sconf.py; nmtf/nmtf.py:62-80): same couplings, same order, same printed strengths."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sconf.npz"), allow_pickle=False)
+    for name in z["names"]:
+        S = z[f"S_{name}"]
+        cols, rows, vals, lines = oc.s_matrix_confusion(S)
+        assert lines == z[f"lines_{name}"].tolist()
+        assert np.array_equal(vals, S[rows, cols]) and np.all(np.diff(vals) <= 0)
+        assert sorted(cols.tolist()) == list(range(S.shape[1]))

@@ -1,0 +1,46 @@
+"""mnmf_gram_static -- the entry point that allocates nothing (include/mnmf.h) -- against mnmf_gram through the C-ABI:
+two calls in a row on one context, the second with a smaller input (the static scratch keeps the first call's
+partials), then a k beyond the static limit.  Tolerances are the kernel-level ones of DESIGN.md section 2 (fp64 1e-12,
+fp32 2e-6 relative Frobenius): the two entry points sum in different orders."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+def test_gram_static_matches_gram_twice_second_smaller(dtype):
+    import torch
+
+    from manta_amd import _lib
+    from manta_amd.engine import Engine, MnmfError
+
+    lib = _lib.load()
+    eng = Engine(device=0, dtype=dtype)
+    tol = 1e-12 if dtype == "fp64" else 2e-6
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    try:
+        for rows, k, with_b in ((300_000, 50, False), (70_001, 50, True), (513, 7, False), (5, 200, True), (0, 9, False)):
+            A = torch.rand((rows, k), generator=g, device="cuda", dtype=eng.tdtype)
+            B = torch.rand((rows, k), generator=g, device="cuda", dtype=eng.tdtype) if with_b else None
+            want = eng.gram(A, B)                                           # the existing entry point (mnmf_gram)
+            out = torch.full((k, k), float("nan"), device="cuda", dtype=eng.tdtype)
+            before = torch.cuda.memory_allocated()
+            rc = lib.mnmf_gram_static(eng._h, rows, k, A.data_ptr(), B.data_ptr() if with_b else None, out.data_ptr())
+            assert rc == 0, lib.mnmf_last_error(eng._h)
+            torch.cuda.synchronize()
+            assert torch.cuda.memory_allocated() == before
+            ref = (A.double().T @ (B if with_b else A).double())
+            scale = max(float(ref.norm()), 1e-300)
+            assert float((out.double() - want.double()).norm()) <= tol * scale, (rows, k)
+            assert float((out.double() - ref).norm()) <= tol * scale, (rows, k)
+        A = torch.rand((64, 300), generator=g, device="cuda", dtype=eng.tdtype)
+        out = torch.empty((300, 300), device="cuda", dtype=eng.tdtype)
+        rc = lib.mnmf_gram_static(eng._h, 64, 300, A.data_ptr(), None, out.data_ptr())
+        assert rc == _lib.MNMF_EINVAL if hasattr(_lib, "MNMF_EINVAL") else rc == -1
+        assert b"exceeds the static scratch" in lib.mnmf_last_error(eng._h)
+    finally:
+        eng.close()

@@ -39,4 +39,7 @@ for k, (calls, us) in sorted(dur.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     wb = write.get(k, 0.0) * 1024
     rows.append(dict(kernel=k, calls=calls, avg_us=round(us, 1), fetch_MB_corrected=round(fb / 1e6, 1),
                      write_MB=round(wb / 1e6, 1), hbm_GBps=round((fb + wb) / (us * 1e-6) / 1e9, 1) if us else 0))
-print(json.dumps(rows, indent=1))
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import source_fingerprint  # noqa: E402
+print(json.dumps({"source_sha": source_fingerprint(), "kernels": rows}, indent=1))
