@@ -75,6 +75,7 @@ struct Tune {
   int fuse_grams = 1;                 // Grams of the new factor / of |new - old| inside the update kernel (k <= 64)
   int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
+  int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
   Tune() {
@@ -106,6 +107,7 @@ struct Tune {
     mfma_rk = (int)geti("MNMF_MFMA_RK", mfma_rk);
     fuse_grams = (int)geti("MNMF_FUSE_GRAMS", fuse_grams);
     lds_pad = (int)geti("MNMF_LDS_PAD", lds_pad);
+    xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
   }
 };
@@ -437,7 +439,7 @@ class Engine : public ImplBase {
     E_HIP(Xth.cols.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * 4));
     E_HIP(Xth.vals.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * sizeof(T)));
     // a word is cut at document-block boundaries only if its pieces stay long enough to pay for their carry slots
-    const int32_t long_df = (int32_t)std::min<int64_t>(std::max<int64_t>(kSubPiece, (int64_t)tune.xt_min_piece * n_blocks), 1 << 30);
+    const int32_t long_df = (int32_t)std::min<int64_t>(std::max<int64_t>(tune.xt_long_floor, (int64_t)tune.xt_min_piece * n_blocks), 1 << 30);
     transpose_key_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), rowid.template as<uint32_t>(),
                                                                    df.template as<int32_t>(), nnz, V, bs, n_blocks,
                                                                    long_df, (uint32_t)n_hot, (uint32_t)tile_rows,

@@ -51,11 +51,9 @@ def engines():
 
 
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
-@pytest.mark.parametrize("k", [1, 5, 7, 10, 20, 50, 64, 100, 130, 260])
+@pytest.mark.parametrize("k", [1, 5, 7, 10, 20, 50, 64, 100, 130, 260, 600])
 def test_spmm_both_directions(engines, dtype, k):
-    eng = engines[dtype]
-    if dtype == "fp64" and k > 256:
-        pytest.skip("k > 256 unsupported in fp64")
+    eng = engines[dtype]   # k = 260 (fp64) and 600 (both): wider than a wave covers -> column chunks
     X = make_x(1500, 700, seed=k)
     assert (np.diff(X.tocsc().indptr) > 512).any(), "want at least one chunked (long) row in X^T"
     eng.set_matrix(X)
