@@ -77,6 +77,17 @@ typedef struct {
  * (it is single-process); the Python side implements it with torch.distributed (RCCL). */
 typedef int (*mnmf_allreduce_fn)(void* user, void* dev_ptr, int64_t count, int dtype, void* stream);
 
+/* Collective hook with the three operations of the document-sharded schedule.  All of them
+ * work IN PLACE on device memory of the engine, ordered after prior work on `stream` and before later work on it:
+ *   MNMF_COMM_ALLREDUCE       dev_ptr[0 .. count)                      <- sum over ranks
+ *   MNMF_COMM_REDUCE_SCATTER  dev_ptr = n_ranks blocks of `count` elements; block `rank` <- sum over ranks of that
+ *                             block (the other blocks are left unspecified)
+ *   MNMF_COMM_ALLGATHER       dev_ptr = n_ranks blocks of `count` elements; block r <- rank r's block r
+ * Return 0 on success.  No counterpart in the reference; the Python side implements it with torch.distributed on
+ * tensors that alias the engine's buffers (RCCL: reduce_scatter_tensor / all_gather_into_tensor, no staging copy). */
+enum { MNMF_COMM_ALLREDUCE = 0, MNMF_COMM_REDUCE_SCATTER = 1, MNMF_COMM_ALLGATHER = 2 };
+typedef int (*mnmf_comm_fn)(void* user, int op, void* dev_ptr, int64_t count, int dtype, void* stream);
+
 /* -- lifetime ---------------------------------------------------------------------------- */
 /* Create a context on GPU `device`, computing in `dtype`, enqueuing on `hip_stream`
  * (a hipStream_t; NULL = the default stream). */
@@ -91,6 +102,12 @@ int mnmf_row_stride(const mnmf_ctx* ctx, int k);
 
 /* Install (or clear, fn==NULL) the all-reduce hook.  `n_ranks` is informational (byte model). */
 int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ranks);
+
+/* Install (or clear, fn==NULL) the collective hook; `rank` in [0, n_ranks).  With it, standard NMF and NMTF exchange
+ * the k x V partial by reduce-scatter, update only this rank's slice of H^T and all-gather the result (instead of
+ * all-reduce + the whole update on every rank); Projective NMF, whose next product needs the summed matrix itself,
+ * keeps the all-reduce. */
+int mnmf_set_comm(mnmf_ctx* ctx, mnmf_comm_fn fn, void* user, int rank, int n_ranks);
 
 /* -- the matrix -------------------------------------------------------------------------- */
 /* Give the engine this rank's rows of X as CSR (replaces `in_mat.tocsr()` being handed to the

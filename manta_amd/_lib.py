@@ -33,6 +33,8 @@ class MnmfSegments(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+COMM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+COMM_ALLREDUCE, COMM_REDUCE_SCATTER, COMM_ALLGATHER = 0, 1, 2
 
 # every symbol include/mnmf.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -42,6 +44,7 @@ SIGNATURES = {
     "mnmf_version": (C.c_char_p, []),
     "mnmf_row_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "mnmf_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]),
+    "mnmf_set_comm": (C.c_int, [C.c_void_p, COMM_FN, C.c_void_p, C.c_int, C.c_int]),
     "mnmf_set_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mnmf_run_nmf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),
     "mnmf_run_pnmf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),

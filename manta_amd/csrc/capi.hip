@@ -100,6 +100,19 @@ int mnmf_set_allreduce(mnmf_ctx* ctx, mnmf_allreduce_fn fn, void* user, int n_ra
   return ctx->impl->hook_changed();
 }
 
+int mnmf_set_comm(mnmf_ctx* ctx, mnmf_comm_fn fn, void* user, int rank, int n_ranks) {
+  if (!ctx) return MNMF_EINVAL;
+  if (fn && (n_ranks < 1 || rank < 0 || rank >= n_ranks)) {
+    ctx->fail(MNMF_EINVAL, "set_comm: rank must be in [0, n_ranks)");
+    return MNMF_EINVAL;
+  }
+  ctx->comm = fn;
+  ctx->comm_user = user;
+  ctx->rank = fn ? rank : 0;
+  ctx->n_ranks = fn ? n_ranks : 1;
+  return ctx->impl->hook_changed();
+}
+
 int mnmf_set_matrix(mnmf_ctx* ctx, int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                     const void* vals, int on_device) {
   if (!ctx) return MNMF_EINVAL;

@@ -12,9 +12,13 @@ struct mnmf_ctx {
   int dtype = MNMF_F32;
   hipStream_t stream = nullptr;
   std::string err;
-  mnmf_allreduce_fn ar = nullptr;
+  mnmf_allreduce_fn ar = nullptr;   // all-reduce only (mnmf_set_allreduce)
   void* ar_user = nullptr;
+  mnmf_comm_fn comm = nullptr;      // all-reduce / reduce-scatter / all-gather (mnmf_set_comm); wins over `ar`
+  void* comm_user = nullptr;
+  int rank = 0;
   int n_ranks = 1;
+  bool sharded() const { return ar != nullptr || comm != nullptr; }
   ImplBase* impl = nullptr;
   void fail(int, const std::string& msg) { err = msg; }
 };

@@ -77,6 +77,7 @@ struct Tune {
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
+  int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
@@ -109,6 +110,7 @@ struct Tune {
     lds_pad = (int)geti("MNMF_LDS_PAD", lds_pad);
     xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
+    rs_ag = (int)geti("MNMF_RS_AG", rs_ag);
   }
 };
 
@@ -334,7 +336,7 @@ class Engine : public ImplBase {
   int ensure_prepared() {
     if (prepared) return 0;
     renumbered = false;
-    if (!tune.permute_vocab || (nnz == 0 && !ctx->ar)) {
+    if (!tune.permute_vocab || (nnz == 0 && !ctx->sharded())) {
       prepared = true;
       return 0;
     }
@@ -966,9 +968,53 @@ class Engine : public ImplBase {
   }
 
   int allreduce(T* p, int64_t count) {
+    if (ctx->comm) return collective(MNMF_COMM_ALLREDUCE, p, count);
     if (!ctx->ar) return 0;
     const int r = ctx->ar(ctx->ar_user, p, count, ctx->dtype, (void*)st());
     if (r != 0) return fail(MNMF_ECOMM, "all-reduce hook failed with code " + std::to_string(r));
+    return 0;
+  }
+  int collective(int op, T* p, int64_t count) {
+    const int r = ctx->comm(ctx->comm_user, op, p, count, ctx->dtype, (void*)st());
+    if (r != 0) return fail(MNMF_ECOMM, "collective hook (op " + std::to_string(op) + ") failed with code " + std::to_string(r));
+    return 0;
+  }
+
+  // ---- reduce-scatter -> slice update -> all-gather
+  // The vocabulary rows of the exchanged V x ld matrices are cut into n_ranks equal slices of slice_rows() rows (the
+  // buffers are allocated with the padded row count and the padding rows stay zero: the SpMM never writes them and a
+  // multiplicative update of a zero row is zero).  Rank r owns rows [r * slice_rows, (r + 1) * slice_rows).
+  bool use_slices() const { return ctx->comm != nullptr && ctx->n_ranks > 1 && tune.rs_ag; }
+  int64_t slice_rows() const { return use_slices() ? cdiv(V, ctx->n_ranks) : V; }
+  int64_t padded_V() const { return use_slices() ? slice_rows() * ctx->n_ranks : V; }
+  // live columns on the wire only when at least a quarter of a padded row is padding (as allreduce_rows)
+  bool pack_rows(int k, int ld) const { return tune.pack_exchange && (ld - k) * 4 >= ld; }
+  // buf (padded_V x ld): every rank holds a partial; afterwards this rank's slice holds the sum over ranks
+  int reduce_scatter_rows(T* buf, int k, int ld) {
+    const int64_t Vs = slice_rows(), Vp = padded_V();
+    if (!pack_rows(k, ld)) return collective(MNMF_COMM_REDUCE_SCATTER, buf, Vs * ld);
+    E_HIP(ar_pack.ensure((size_t)Vp * k * sizeof(T)));
+    T* q = ar_pack.template as<T>();
+    unpad_rows_kernel<T><<<(unsigned)cdiv(Vp * k, 256), 256, 0, st()>>>(buf, Vp, k, ld, T(0), q);
+    E_LAUNCH();
+    MNMF_TRY(collective(MNMF_COMM_REDUCE_SCATTER, q, Vs * k));
+    const int64_t lo = Vs * ctx->rank;
+    pad_rows_kernel<T><<<(unsigned)cdiv(Vs * ld, 256), 256, 0, st()>>>(q + lo * k, Vs, k, ld, buf + lo * ld);
+    E_LAUNCH();
+    return 0;
+  }
+  // buf (padded_V x ld): this rank's slice is current; afterwards every slice holds its owner's rows
+  int all_gather_rows(T* buf, int k, int ld) {
+    const int64_t Vs = slice_rows(), Vp = padded_V();
+    if (!pack_rows(k, ld)) return collective(MNMF_COMM_ALLGATHER, buf, Vs * ld);
+    E_HIP(ar_pack.ensure((size_t)Vp * k * sizeof(T)));
+    T* q = ar_pack.template as<T>();
+    const int64_t lo = Vs * ctx->rank;
+    unpad_rows_kernel<T><<<(unsigned)cdiv(Vs * k, 256), 256, 0, st()>>>(buf + lo * ld, Vs, k, ld, T(0), q + lo * k);
+    E_LAUNCH();
+    MNMF_TRY(collective(MNMF_COMM_ALLGATHER, q, Vs * k));
+    pad_rows_kernel<T><<<(unsigned)cdiv(Vp * ld, 256), 256, 0, st()>>>(q, Vp, k, ld, buf);
+    E_LAUNCH();
     return 0;
   }
 
@@ -978,7 +1024,7 @@ class Engine : public ImplBase {
   // a sharded iteration that nothing can hide.  Below 25 % padding (k = 50: 22 %) the two copy kernels cost about what
   // the shorter message saves, and the buffer goes out as it is.
   int allreduce_rows(T* p, int64_t count, int k, int ld) {
-    if (!ctx->ar) return 0;
+    if (!ctx->sharded()) return 0;
     if (!tune.pack_exchange || count % ld != 0 || (ld - k) * 4 < ld) return allreduce(p, count);  // < 25 % padding: as is
     const int64_t rows = count / ld;
     E_HIP(ar_pack.ensure((size_t)rows * k * sizeof(T)));
@@ -1131,7 +1177,11 @@ class Engine : public ImplBase {
     const double eps = (o && o->eps >= 0) ? o->eps : 1e-10;
     const double zthr = (o && o->zero_threshold >= 0) ? o->zero_threshold : 1e-5;
     const bool finalize = !o || o->finalize;
-    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)V * ld * sizeof(T);
+    const bool sliced = use_slices();  // sharded: reduce-scatter -> update of this rank's slice of H^T -> all-gather
+    const int64_t Vp = padded_V(), Vs = slice_rows();
+    const int64_t s_lo = sliced ? Vs * ctx->rank : 0;
+    const int64_t s_rows = sliced ? std::max<int64_t>(0, std::min<int64_t>(Vs, V - s_lo)) : V;
+    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)Vp * ld * sizeof(T);
     const size_t gsz = (size_t)ld * ld * sizeof(T);
     for (int i = 0; i < 2; ++i) {
       E_HIP(Wb[i].ensure(wsz));
@@ -1141,9 +1191,15 @@ class Engine : public ImplBase {
     E_HIP(Ex.ensure(hsz + gsz));       // [Nh (V x ld) | WtW (ld x ld)]: one all-reduce
     E_HIP(small.ensure(4 * gsz));      // HHt, dW gram, dH gram
     T* Nh = Ex.template as<T>();
-    T* Gw = Nh + (size_t)V * ld;
+    T* Gw = Nh + (size_t)Vp * ld;
     T* Gh = small.template as<T>();
     T* Gd = Gh + (size_t)ld * ld;      // [dW gram | dH gram] contiguous
+    if (Vp > V) {  // the padding rows of the sliced buffers are zero and stay zero
+      const size_t off = (size_t)V * ld * sizeof(T), len = (size_t)(Vp - V) * ld * sizeof(T);
+      E_HIP(hipMemsetAsync(Hb[0].template as<char>() + off, 0, len, st()));
+      E_HIP(hipMemsetAsync(Hb[1].template as<char>() + off, 0, len, st()));
+      E_HIP(hipMemsetAsync(Ex.template as<char>() + off, 0, len, st()));
+    }
     MNMF_TRY(load_W(W, k, ld, Wb[0].template as<T>()));
     MNMF_TRY(load_H(H, k, ld, Hb[0].template as<T>()));
     int cw = 0, ch = 0;
@@ -1180,9 +1236,21 @@ class Engine : public ImplBase {
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
       pt.mark(1);
-      MNMF_TRY(allreduce_rows(Nh, (int64_t)V * ld + (int64_t)ld * ld, k, ld));
-      // h update :41-42, with h_hT of the new h (:44) and, for the norms, D^T D of D = |h - h_old| (:53) in the same pass
-      MNMF_TRY(rk_grams(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps, Gh, do_check ? Gd + (size_t)ld * ld : nullptr));
+      if (sliced) {
+        // every rank sums and updates one slice of the vocabulary, then the slices are gathered: the same bytes on
+        // the wire as an all-reduce, the h update done once instead of n_ranks times, h identical on every rank
+        MNMF_TRY(allreduce(Gw, (int64_t)ld * ld));
+        MNMF_TRY(reduce_scatter_rows(Nh, k, ld));
+        const size_t o = (size_t)s_lo * ld;
+        MNMF_TRY(rk(RK_MU, Hc + o, Gw, nullptr, nullptr, Hc + o, Nh + o, Hn + o, s_rows, ld, eps));    // :41-42
+        MNMF_TRY(all_gather_rows(Hn, k, ld));
+        MNMF_TRY(gram(Hn, nullptr, Hn, nullptr, V, ld, false, Gh));                                     // :44
+        if (do_check) MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + (size_t)ld * ld));                // :53
+      } else {
+        MNMF_TRY(allreduce_rows(Nh, (int64_t)V * ld + (int64_t)ld * ld, k, ld));
+        // h update :41-42, with h_hT of the new h (:44) and, for the norms, D^T D of D = |h - h_old| (:53) in the same pass
+        MNMF_TRY(rk_grams(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps, Gh, do_check ? Gd + (size_t)ld * ld : nullptr));
+      }
       pt.mark(2);
       MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                            // in_mat @ h.T         :45
       pt.mark(4);
@@ -1397,7 +1465,11 @@ class Engine : public ImplBase {
     const double eps = (o && o->eps >= 0) ? o->eps : 1e-9;
     const double zthr = (o && o->zero_threshold >= 0) ? o->zero_threshold : 1e-5;
     const bool finalize = !o || o->finalize;
-    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)V * ld * sizeof(T);
+    const bool sliced = use_slices();  // sharded: reduce-scatter -> S and this rank's slice of H^T -> all-gather
+    const int64_t Vp = padded_V(), Vs = slice_rows();
+    const int64_t s_lo = sliced ? Vs * ctx->rank : 0;
+    const int64_t s_rows = sliced ? std::max<int64_t>(0, std::min<int64_t>(Vs, V - s_lo)) : V;
+    const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)Vp * ld * sizeof(T);
     const size_t gel = (size_t)ld * ld, gsz = gel * sizeof(T);
     for (int i = 0; i < 2; ++i) {
       E_HIP(Wb[i].ensure(wsz));
@@ -1408,7 +1480,13 @@ class Engine : public ImplBase {
     E_HIP(Aux1.ensure(hsz));         // M1 = hT sT, later M2 = Pt s1
     E_HIP(small.ensure(16 * gsz));
     T* Pt = Ex.template as<T>();
-    T* Gw1 = Pt + (size_t)V * ld;
+    T* Gw1 = Pt + (size_t)Vp * ld;
+    if (Vp > V) {  // the padding rows of the sliced buffers are zero and stay zero
+      const size_t off = (size_t)V * ld * sizeof(T), len = (size_t)(Vp - V) * ld * sizeof(T);
+      E_HIP(hipMemsetAsync(Hb[0].template as<char>() + off, 0, len, st()));
+      E_HIP(hipMemsetAsync(Hb[1].template as<char>() + off, 0, len, st()));
+      E_HIP(hipMemsetAsync(Ex.template as<char>() + off, 0, len, st()));
+    }
     T* M1 = Aux1.template as<T>();
     T* sm = small.template as<T>();
     T* Sb[2] = {sm, sm + gel};
@@ -1496,19 +1574,34 @@ class Engine : public ImplBase {
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wn, ld, Pt));                                    // (w1.T @ in_mat)^T
       pt.mark(1);
-      MNMF_TRY(allreduce_rows(Pt, (int64_t)V * ld + (int64_t)gel, k, ld));
-      MNMF_TRY(gram(Pt, nullptr, Hc, nullptr, V, ld, false, num_s));    // (w1.T X) @ h.T
+      const size_t so = (size_t)s_lo * ld;   // this rank's slice of the vocabulary rows (everything when not sliced)
+      if (sliced) {
+        MNMF_TRY(allreduce(Gw1, (int64_t)gel));
+        MNMF_TRY(reduce_scatter_rows(Pt, k, ld));
+        MNMF_TRY(gram(Pt + so, nullptr, Hc + so, nullptr, s_rows, ld, false, num_s));   // this slice's share of (w1.T X) @ h.T
+        MNMF_TRY(allreduce(num_s, (int64_t)gel));
+      } else {
+        MNMF_TRY(allreduce_rows(Pt, (int64_t)V * ld + (int64_t)gel, k, ld));
+        MNMF_TRY(gram(Pt, nullptr, Hc, nullptr, V, ld, false, num_s));  // (w1.T X) @ h.T
+      }
       MNMF_TRY(kxk(Gw1, Sc, T2, ld, 0, 0));
       MNMF_TRY(kxk(T2, hhT, den_s, ld, 0, 0));                           // (w1T w1) s (h hT)
       kxk_mu_kernel<T><<<kb, 256, 0, st()>>>(Sc, num_s, den_s, (T)eps, Sn, ld);
       E_LAUNCH();
       pt.mark(3);
       // ---- H update                                                   nmtf.py:161-163
-      MNMF_TRY(rk(RK_PROD, Pt, Sn, nullptr, nullptr, nullptr, nullptr, M1, V, ld, 0));  // (s1.T @ P)^T = Pt s1
+      MNMF_TRY(rk(RK_PROD, Pt + so, Sn, nullptr, nullptr, nullptr, nullptr, M1 + so, s_rows, ld, 0));  // (s1.T @ P)^T = Pt s1
       MNMF_TRY(kxk(Sn, Gw1, T3, ld, 1, 0));                              // s1T (w1T w1)
       MNMF_TRY(kxk(T3, Sn, Qm, ld, 0, 0));                               // s1T (w1T w1) s1   (symmetric)
-      // h update with the next iteration's h @ h.T (:152) and D^T D of D = |h1 - h| (:181) in the same pass
-      MNMF_TRY(rk_grams(RK_MU, Hc, Qm, nullptr, nullptr, Hc, M1, Hn, V, ld, eps, hhT, do_check ? Gd + gel : nullptr));
+      if (sliced) {
+        MNMF_TRY(rk(RK_MU, Hc + so, Qm, nullptr, nullptr, Hc + so, M1 + so, Hn + so, s_rows, ld, eps));
+        MNMF_TRY(all_gather_rows(Hn, k, ld));
+        MNMF_TRY(gram(Hn, nullptr, Hn, nullptr, V, ld, false, hhT));                                   // :152
+        if (do_check) MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + gel));                           // :181
+      } else {
+        // h update with the next iteration's h @ h.T (:152) and D^T D of D = |h1 - h| (:181) in the same pass
+        MNMF_TRY(rk_grams(RK_MU, Hc, Qm, nullptr, nullptr, Hc, M1, Hn, V, ld, eps, hhT, do_check ? Gd + gel : nullptr));
+      }
       hht_valid = true;
       pt.mark(2);
       if (do_check) {                                                     // Frobenius norms   nmtf.py:179-181

@@ -29,7 +29,8 @@ def shard_csr(X, rank: int, world: int):
     return X[lo:hi], lo, hi
 
 
-def run_sharded(method: str, X_local, W0_local, H0, S0=None, *, dtype="fp64", device=None, group=None, **opts):
+def run_sharded(method: str, X_local, W0_local, H0, S0=None, *, dtype="fp64", device=None, group=None,
+                collectives=True, **opts):
     """Run one solver on this rank's document shard; returns (W_local, H[, S], stats).
     Requires an initialised torch.distributed process group (nccl on GPUs)."""
     from .engine import Engine
@@ -37,7 +38,7 @@ def run_sharded(method: str, X_local, W0_local, H0, S0=None, *, dtype="fp64", de
     eng = Engine(device=device, dtype=dtype)
     try:
         eng.set_matrix(X_local)
-        eng.set_process_group(group)
+        eng.set_process_group(group, collectives=collectives)
         if method == "nmf":
             return eng.run_nmf(W0_local, H0, **opts)
         if method == "pnmf":

@@ -144,41 +144,82 @@ class Engine:
         return lo, hi
 
     # ------------------------------------------------------------------ multi-GPU hook
-    def set_process_group(self, group=None):
-        """Install a sum-all-reduce hook over ``torch.distributed`` (nccl = RCCL over xGMI; with the
-        gloo backend the exchange is staged through the host, for tests)."""
+    def _alias(self, ptr, count):
+        """A torch tensor over `count` elements of the engine's own device memory at `ptr` (no copy): what the
+        collectives of torch.distributed operate on in place."""
+        class _DevMem:
+            pass
+        holder = _DevMem()
+        holder.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4" if self.dtype == "fp32" else "<f8",
+                                           "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(holder, device=self.device)
+
+    def set_process_group(self, group=None, collectives=True):
+        """Install the collective hook over ``torch.distributed`` (nccl = RCCL over xGMI): all-reduce,
+        reduce-scatter and all-gather run IN PLACE on tensors that alias the engine's exchange buffers, no staging
+        copies.  With the gloo backend (tests: several ranks on one GPU) the same operations are staged through the
+        host.  ``collectives=False`` installs the older all-reduce-only hook (all-reduce + replicated H update)."""
         import torch.distributed as dist
 
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            self._lib.mnmf_set_comm(self._h, C.cast(None, _lib.COMM_FN), None, 0, 1)
             self._lib.mnmf_set_allreduce(self._h, C.cast(None, _lib.ALLREDUCE_FN), None, 1)
             self._hook = None
             return
         backend = dist.get_backend(group)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
         eng = self
+        SUM = dist.ReduceOp.SUM
 
-        def hook(_user, ptr, count, _dtype, _stream):
-            try:
-                if eng._stage is None or eng._stage.numel() < count:
-                    eng._stage = torch.empty(int(count), dtype=eng.tdtype, device=eng.device)
-                buf = eng._stage[:count]
-                nbytes = count * buf.element_size()
-                if eng._lib.mnmf_memcpy_d2d(eng._h, buf.data_ptr(), ptr, nbytes) != 0:
-                    return 1
-                if backend == "nccl":
-                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        def run(op, ptr, count):
+            n = count if op == _lib.COMM_ALLREDUCE else count * world
+            t = eng._alias(ptr, n)
+            mine = t[rank * count:(rank + 1) * count] if op != _lib.COMM_ALLREDUCE else None
+            if backend == "nccl":
+                if op == _lib.COMM_ALLREDUCE:
+                    dist.all_reduce(t, op=SUM, group=group)
+                elif op == _lib.COMM_REDUCE_SCATTER:
+                    dist.reduce_scatter_tensor(mine, t, op=SUM, group=group)     # in place: recv = send + rank * count
                 else:
-                    host = buf.cpu()
-                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-                    buf.copy_(host)
-                if eng._lib.mnmf_memcpy_d2d(eng._h, ptr, buf.data_ptr(), nbytes) != 0:
-                    return 2
+                    dist.all_gather_into_tensor(t, mine, group=group)            # in place: send = recv + rank * count
+                return
+            # gloo: through the host (correctness rehearsal only)
+            if op == _lib.COMM_ALLGATHER:
+                parts = [torch.empty(count, dtype=eng.tdtype) for _ in range(world)]
+                dist.all_gather(parts, mine.cpu(), group=group)
+                t.copy_(torch.cat(parts))
+                return
+            host = t.cpu()
+            dist.all_reduce(host, op=SUM, group=group)
+            if op == _lib.COMM_ALLREDUCE:
+                t.copy_(host)
+            else:
+                mine.copy_(host[rank * count:(rank + 1) * count])
+
+        def comm_hook(_user, op, ptr, count, _dtype, _stream):
+            try:
+                run(int(op), ptr, int(count))
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
+                print(f"[manta_amd] collective hook failed: {e!r}", flush=True)
+                return 3
+
+        def ar_hook(_user, ptr, count, _dtype, _stream):
+            try:
+                run(_lib.COMM_ALLREDUCE, ptr, int(count))
+                return 0
+            except Exception as e:
                 print(f"[manta_amd] all-reduce hook failed: {e!r}", flush=True)
                 return 3
 
-        self._hook = _lib.ALLREDUCE_FN(hook)
-        self._check(self._lib.mnmf_set_allreduce(self._h, self._hook, None, dist.get_world_size(group)))
+        if collectives:
+            self._hook = _lib.COMM_FN(comm_hook)
+            self._lib.mnmf_set_allreduce(self._h, C.cast(None, _lib.ALLREDUCE_FN), None, 1)
+            self._check(self._lib.mnmf_set_comm(self._h, self._hook, None, rank, world))
+        else:
+            self._hook = _lib.ALLREDUCE_FN(ar_hook)
+            self._lib.mnmf_set_comm(self._h, C.cast(None, _lib.COMM_FN), None, 0, 1)
+            self._check(self._lib.mnmf_set_allreduce(self._h, self._hook, None, world))
 
     # ------------------------------------------------------------------ solvers
     def run_nmf(self, W0, H0, **kw):

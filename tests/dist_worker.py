@@ -3,7 +3,11 @@
 mode=emulate (CPU, gloo): every rank runs the engine's per-rank schedule in numpy on its document
 shard and sums exactly what engine.hip all-reduces, at the same points; the result must equal the
 unsharded oracle.  This pins the sharding algorithm (what is exchanged, and when).
-mode=engine (GPU): the real HIP engine, two ranks on one GPU, exchange staged through gloo.
+mode=emulate_rsag (CPU, gloo): the reduce-scatter -> slice update -> all-gather schedule of nmf / nmtf
+(engine.hip use_slices(); pnmf keeps its all-reduce): vocabulary rows cut into world equal slices (zero padded),
+each rank sums and updates its slice only, the slices are gathered.
+mode=engine / engine_ar (GPU): the real HIP engine, two ranks on one GPU, exchange staged through gloo; with the
+collective hook (reduce-scatter / all-gather) or the all-reduce-only hook.
 """
 import os
 import sys
@@ -25,6 +29,66 @@ def allreduce(a):
     t = torch.from_numpy(np.ascontiguousarray(a))
     dist.all_reduce(t)
     return t.numpy()
+
+
+def reduce_scatter_rows(a, rank, world):
+    """a: (Vp, k) partial on every rank, Vp = world * Vs -> this rank's (Vs, k) slice of the sum."""
+    Vs = a.shape[0] // world
+    parts = [torch.from_numpy(np.ascontiguousarray(a[r * Vs:(r + 1) * Vs])) for r in range(world)]
+    out = torch.empty_like(parts[0])
+    for r in range(world):      # gloo has no reduce_scatter: one reduce per destination, same result
+        buf = parts[r].clone()
+        dist.reduce(buf, dst=r)
+        if r == rank:
+            out = buf
+    return out.numpy()
+
+
+def all_gather_rows(mine, world):
+    t = torch.from_numpy(np.ascontiguousarray(mine))
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return np.concatenate([p.numpy() for p in parts])
+
+
+def emulate_rsag(method, X, W, H, S, N):
+    """engine.hip with use_slices(): what is exchanged, by which collective, and who updates what."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    k, V = H.shape
+    Vs = -(-V // world)
+    Vp = Vs * world
+    lo = Vs * rank
+    n_own = max(0, min(Vs, V - lo))
+
+    def pad(a):                                  # (V, k) -> (Vp, k), zero rows behind
+        return np.concatenate([a, np.zeros((Vp - V, a.shape[1]))])
+
+    Ht = pad(H.T.copy())                         # the engine keeps H transposed
+    if method == "nmf":
+        for _ in range(N):
+            wtw = allreduce(W.T @ W)                                              # small all-reduce
+            num = reduce_scatter_rows(pad(X.T @ W), rank, world)                  # this rank's slice of X^T W, summed
+            mine = Ht[lo:lo + Vs].copy()
+            mine[:n_own] = mine[:n_own] * (num[:n_own] / (mine[:n_own] @ wtw + oc.NMF_EPS))   # (wtw @ h).T = h.T @ wtw
+            Ht = all_gather_rows(mine, world)
+            Hn = Ht[:V]
+            W = W * ((X @ Hn) / (W @ (Hn.T @ Hn) + oc.NMF_EPS))                   # h @ h.T replicated from the gathered h
+        return {"W": W, "H": Ht[:V].T.copy()}
+    assert method == "nmtf"
+    for _ in range(N):
+        Hn = Ht[:V]
+        hhT = Hn.T @ Hn
+        W1 = W * ((X @ (Hn @ S.T)) / (W @ (S @ hhT @ S.T) + oc.NMTF_EPS))
+        g = allreduce(W1.T @ W1)
+        Pt = reduce_scatter_rows(pad(X.T @ W1), rank, world)                      # slice of (w1.T X).T
+        own = Ht[lo:lo + Vs]
+        num_s = allreduce(Pt[:n_own].T @ own[:n_own])                             # slice share of (w1.T X) @ h.T
+        S1 = S * (num_s / (g @ S @ hhT + oc.NMTF_EPS))
+        mine = own.copy()
+        mine[:n_own] = own[:n_own] * ((Pt[:n_own] @ S1) / (own[:n_own] @ (S1.T @ g @ S1) + oc.NMTF_EPS))
+        Ht = all_gather_rows(mine, world)
+        W, S = W1, S1
+    return {"W": W, "S": S, "H": Ht[:V].T.copy()}
 
 
 def emulate(method, X, W, H, S, N):
@@ -83,12 +147,17 @@ def main():
     if mode == "emulate":
         got = emulate(method, Xl.tocsr(), W0[lo:hi].copy(), H0.copy(), S0.copy(), N)
         tol = 1e-11
+    elif mode == "emulate_rsag":
+        got = emulate_rsag(method, Xl.tocsr(), W0[lo:hi].copy(), H0.copy(), S0.copy(), N)
+        tol = 1e-11
     else:
         from manta_amd.dist import run_sharded
 
         dtype = sys.argv[3]
         kw = dict(fixed_iters=N, zero_threshold=0.0) if method != "pnmf" else dict(fixed_iters=N)
-        res = run_sharded(method, Xl, W0[lo:hi], H0, S0, dtype=dtype, device=0, **kw)
+        if len(sys.argv) > 4 and sys.argv[4] == "check":      # with the convergence Grams exchanged every iteration
+            kw["force_check"] = True
+        res = run_sharded(method, Xl, W0[lo:hi], H0, S0, dtype=dtype, device=0, collectives=(mode == "engine"), **kw)
         keys = ["W", "S", "H"] if method == "nmtf" else ["W", "H"]
         got = {k_: v.cpu().double().numpy() for k_, v in zip(keys, res[:-1])}
         tol = 1e-10 if dtype == "fp64" else 1e-4

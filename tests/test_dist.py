@@ -11,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(args, port):
+def launch(args, port, nproc=2):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -46,11 +46,37 @@ def test_sharded_schedule_gloo_cpu(method):
     launch(["emulate", method], 29611 + ["nmf", "pnmf", "nmtf"].index(method))
 
 
+@pytest.mark.parametrize("method", ["nmf", "nmtf"])
+def test_reduce_scatter_schedule_gloo_cpu(method):
+    """reduce-scatter -> slice update -> all-gather: 1200 vocabulary rows do not divide... they do by
+    2; the odd split is covered by the three-rank case below."""
+    launch(["emulate_rsag", method], 29651 + ["nmf", "nmtf"].index(method))
+
+
+def test_reduce_scatter_schedule_three_ranks_uneven_slices():
+    launch(["emulate_rsag", "nmf"], 29655, nproc=3)      # 1200 / 3 = 400; 1000 docs by nnz
+    launch(["emulate_rsag", "nmtf"], 29656, nproc=7)     # 1200 = 7 * 172 - 4: the last slice is padded
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
 @pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
 def test_sharded_engine_two_ranks_one_gpu(method, dtype):
-    launch(["engine", method, dtype], 29631 + ["nmf", "pnmf", "nmtf"].index(method) + (3 if dtype == "fp32" else 0))
+    """collective hook: nmf / nmtf take the reduce-scatter -> slice update -> all-gather schedule"""
+    launch(["engine", method, dtype, "check"], 29631 + ["nmf", "pnmf", "nmtf"].index(method) + (3 if dtype == "fp32" else 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["nmf", "nmtf"])
+def test_sharded_engine_all_reduce_hook_only(method):
+    """the all-reduce-only hook (mnmf_set_allreduce): all-reduce + replicated H update, as in round 1"""
+    launch(["engine_ar", method, "fp64"], 29641 + ["nmf", "nmtf"].index(method))
+
+
+@pytest.mark.gpu
+def test_sharded_engine_three_ranks_padded_slices():
+    launch(["engine", "nmf", "fp32", "check"], 29645, nproc=3)
+    launch(["engine", "nmtf", "fp64"], 29646, nproc=7)
 
 
 @pytest.mark.gpu

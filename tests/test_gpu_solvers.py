@@ -276,7 +276,7 @@ def test_run_nmf_autorank_through_the_gpu_path(golden):
         manta_amd.run_nmf(-1, g["X"], nmf_method="bogus", W0=want["W"], H0=want["H"])
 
 
-FP32_STOP_SLACK = 1   # iterations; see test_run_nmf_converged_fp32_stopping_iteration
+FP32_STOP_SLACK = 0   # measured on MI355X: the fp32 runs stop at the reference's iterations (115 / 45 / 129)
 
 
 @pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
