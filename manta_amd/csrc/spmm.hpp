@@ -168,6 +168,17 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
       cl[x] = q < rem ? MNMF_NT_LOAD(cp + q) : 0u;
       vl[x] = q < rem ? MNMF_NT_LOAD(vp + q) : T(0);
     }
+    // destinations of the next CH pieces of this group: lane li holds dest[j + x*LPR + li].  Like (index, value)
+    // they are fetched one chunk ahead: loaded at the start of the chunk that uses them, the first piece end of
+    // every chunk waited for them with vmcnt(0) -- a full trip to memory, and in the PLAIN / HOT modes a drain of
+    // every gather in flight.  Where the next chunk's list starts is known up front: j advances by the number of
+    // end flags in the current chunk.
+    int dl[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+      const int64_t q = (int64_t)j + x * LPR + li;
+      dl[x] = (rem > 0 && q < a.n_dest) ? a.dest[q] : 0;
+    }
     // Retire the first chunk's loads before the loop: otherwise hipcc, merging "load still pending" from
     // the loop entry with the back edge, puts a vmcnt(0) inside the loop right behind the prefetch of the
     // next chunk and every chunk stalls for a full memory latency.
@@ -181,13 +192,6 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
         cn[x] = q < rem ? MNMF_NT_LOAD(cp + q) : 0u;
         vn[x] = q < rem ? MNMF_NT_LOAD(vp + q) : T(0);
       }
-      // destinations of the next CH pieces of this group: lane li holds dest[j + x*LPR + li]
-      int dl[EPL];
-#pragma unroll
-      for (int x = 0; x < EPL; ++x) {
-        const int64_t q = (int64_t)j + x * LPR + li;
-        dl[x] = (rem > 0 && q < a.n_dest) ? a.dest[q] : 0;
-      }
       const int jbase = j;
       // end-of-piece flags of the whole chunk as wave-level bit masks (bit = holder lane): the per-step
       // "did any group finish a piece" test is then scalar work
@@ -197,6 +201,20 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
       uint64_t gmask = 0;  // bit 0 of every lane group
 #pragma unroll
       for (int g = 0; g < NG; ++g) gmask |= (uint64_t)1 << (g * LPR);
+      int dn[EPL];
+      {
+        int ends = 0;  // pieces of this group that end inside the current chunk
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+          const uint64_t mine = LPR == 64 ? em[x] : (em[x] >> gbase) & (((uint64_t)1 << (LPR & 63)) - 1);
+          ends += __popcll(mine);
+        }
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+          const int64_t q = (int64_t)j + ends + x * LPR + li;
+          dn[x] = (rem > CH && q < a.n_dest) ? a.dest[q] : 0;
+        }
+      }
       static_for<CH / U>([&](auto ib) {
         constexpr int u0 = decltype(ib)::value * U;
         uint32_t c[U];
@@ -260,12 +278,33 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
           const uint64_t eb = em[t % EPL] >> (t / EPL);
           if (eb & gmask) {  // wave-uniform, scalar: some group finished a piece at this step
             const bool endf = (eb >> gbase) & 1;
-            const int idx = j - jbase;  // < CH
-            int d = shfl_i(dl[0], gbase + (idx % LPR));
+            // Destination of each finished piece: entry (j - jbase) of its group's list, i.e. register idx / LPR of
+            // lane idx % LPR of the group.  Picked with v_readlane under a scalar loop over the groups that
+            // finished (usually one): a ds_bpermute here is an LDS operation, and waiting for it drains every
+            // gather the TILE / HOT modes have in flight in the LDS pipe.
+            int d = 0;
+            uint64_t pend = eb & gmask;
+            if (!TILE) {  // vector-memory gathers: nothing of theirs waits behind a ds_bpermute
+              const int idx = j - jbase;
+              d = shfl_i(dl[0], gbase + (idx % LPR));
 #pragma unroll
-            for (int x = 1; x < EPL; ++x) {
-              const int dx = shfl_i(dl[x], gbase + (idx % LPR));
-              d = (idx / LPR == x) ? dx : d;
+              for (int x = 1; x < EPL; ++x) {
+                const int dx = shfl_i(dl[x], gbase + (idx % LPR));
+                d = (idx / LPR == x) ? dx : d;
+              }
+              pend = 0;
+            }
+            while (pend) {
+              const int b = __builtin_ctzll(pend);  // first lane of the group
+              pend &= pend - 1;
+              const int idx = __builtin_amdgcn_readlane(j - jbase, b);  // < CH, uniform inside the group
+              int dg = __builtin_amdgcn_readlane(dl[0], b + (idx % LPR));
+#pragma unroll
+              for (int x = 1; x < EPL; ++x) {
+                const int dx = __builtin_amdgcn_readlane(dl[x], b + (idx % LPR));
+                dg = (idx / LPR == x) ? dx : dg;
+              }
+              d = gbase == b ? dg : d;
             }
             if (endf) {
               // destination of the finished piece: an output row, or a carry slot of a multi-piece row
@@ -293,10 +332,47 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
       for (int x = 0; x < EPL; ++x) {
         cl[x] = cn[x];
         vl[x] = vn[x];
+        dl[x] = dn[x];
       }
     }
   }
   }  // tiles
+}
+
+// Sum of carry slots first + s0, first + s0 + stride, ... (< first + n) into acc, UB slots per batch: the loads of a
+// batch are all issued before the first add (indices past the end are clamped to the last slot and their values
+// dropped; lanes beyond the columns read column 0 and are never stored).  Written this way because hipcc, given the
+// plain loop with its bounds tests, waits for every load before issuing the next one -- one 1 KiB load in flight per
+// wave, 0.6 TB/s on the 660 MB of carries of C3.  The order of the additions is that of the plain loop.
+template <typename T, int LPR, int VPL, int UB>
+__device__ inline void sum_carry_slots(const T* __restrict__ carry, int64_t first, int n, int s0, int stride, int ld, int nc,
+                                       int li, T (&acc)[VPL][VecOf<T>::N]) {
+  constexpr int VEC = VecOf<T>::N;
+  using VT = typename VecOf<T>::type;
+  int cof[VPL];
+#pragma unroll
+  for (int w = 0; w < VPL; ++w) {
+    const int co = (w * LPR + li) * VEC;
+    cof[w] = co < nc ? co : 0;
+  }
+  for (int s = s0; s < n; s += stride * UB) {
+    VT t[UB][VPL];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int su = s + u * stride;
+      const T* cp = carry + (first + (su < n ? su : n - 1)) * ld;
+#pragma unroll
+      for (int w = 0; w < VPL; ++w) t[u][w] = *reinterpret_cast<const VT*>(cp + cof[w]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const bool ok = s + u * stride < n;
+#pragma unroll
+      for (int w = 0; w < VPL; ++w)
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) acc[w][x] += ok ? t[u][w].v[x] : T(0);
+    }
+  }
 }
 
 // One wave per chunked row: out[row] = sum of its carry slots in a fixed order.
@@ -320,18 +396,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t* __restri
   for (int w = 0; w < VPL; ++w)
 #pragma unroll
     for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
-  for (int s = gi; s < n; s += NG) {
-    const T* cp = carry + (first + s) * ld;
-#pragma unroll
-    for (int w = 0; w < VPL; ++w) {
-      const int co = (w * LPR + li) * VEC;
-      if (co < nc) {
-        const VT t = *reinterpret_cast<const VT*>(cp + co);
-#pragma unroll
-        for (int x = 0; x < VEC; ++x) acc[w][x] += t.v[x];
-      }
-    }
-  }
+  sum_carry_slots<T, LPR, VPL, (VPL == 2 ? 4 : 8)>(carry, first, n, gi, NG, ld, nc, li, acc);
 #pragma unroll
   for (int mask = LPR; mask < kWave; mask <<= 1)
 #pragma unroll
@@ -376,19 +441,7 @@ __global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t*
   for (int w = 0; w < VPL; ++w)
 #pragma unroll
     for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
-#pragma unroll 4
-  for (int s = wv * NG + gi; s < n; s += NW * NG) {
-    const T* cp = carry + (first + s) * ld;
-#pragma unroll
-    for (int w = 0; w < VPL; ++w) {
-      const int co = (w * LPR + li) * VEC;
-      if (co < nc) {
-        const VT t = *reinterpret_cast<const VT*>(cp + co);
-#pragma unroll
-        for (int x = 0; x < VEC; ++x) acc[w][x] += t.v[x];
-      }
-    }
-  }
+  sum_carry_slots<T, LPR, VPL, (VPL == 2 ? 4 : 8)>(carry, first, n, wv * NG + gi, NW * NG, ld, nc, li, acc);
 #pragma unroll
   for (int mask = LPR; mask < kWave; mask <<= 1)
 #pragma unroll
