@@ -121,6 +121,15 @@ int mnmf_set_matrix(mnmf_ctx* ctx, int64_t m, int64_t V, int64_t nnz, const int6
 /* -- solvers (device pointers, reference layouts, updated in place) ------------------------ */
 /* Loop A, replaces _basic_nmf (nmf_basic.py:6-93).  W: m x k in/out, H: k x V in/out. */
 int mnmf_run_nmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats);
+/* Loop A for several topic counts at once: what OptimizationPipeline.run_optimization asks for when it calls run_nmf once
+ * per candidate topic count on one matrix (optimization_pipeline.py:105-136, 193-198).  n problems with
+ * ks[0] + ... + ks[n-1] <= 32 (fp32 contexts; the topic counts that share one padded 128-byte factor row) are iterated
+ * together: one pass over X per SpMM serves all of them.  W[p]: m x ks[p], H[p]: ks[p] x V, device pointers, in/out;
+ * stats: n entries (may be NULL).  Every problem stops by the reference's rule on its own norms and its result is
+ * bit-identical to mnmf_run_nmf on that problem alone.  MNMF_EINVAL for fp64 contexts, sharded contexts and batches
+ * whose topic counts add up to more than 32: run those one by one. */
+int mnmf_run_nmf_sweep(mnmf_ctx* ctx, int n, const int32_t* ks, void* const* W, void* const* H, const mnmf_opts* opts,
+                       mnmf_stats* stats);
 /* Loop B, replaces projective_nmf (nmf_projective_basic.py:8-121).  W: in/out, H: out only
  * (= W^T X with the L2-column-normalised W when opts->finalize). */
 int mnmf_run_pnmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mnmf_set_comm": (C.c_int, [C.c_void_p, COMM_FN, C.c_void_p, C.c_int, C.c_int]),
     "mnmf_set_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mnmf_run_nmf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),
+    "mnmf_run_nmf_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.c_void_p]),
     "mnmf_run_pnmf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),
     "mnmf_run_nmtf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MnmfOpts), C.POINTER(MnmfStats)]),
     "mnmf_spmm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -123,6 +123,11 @@ int mnmf_run_nmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, 
   if (!ctx || !W || !H) return MNMF_EINVAL;
   return ctx->impl->run_nmf(k, W, H, opts, stats);
 }
+int mnmf_run_nmf_sweep(mnmf_ctx* ctx, int n, const int32_t* ks, void* const* W, void* const* H, const mnmf_opts* opts,
+                       mnmf_stats* stats) {
+  if (!ctx) return MNMF_EINVAL;
+  return ctx->impl->run_nmf_sweep(n, ks, W, H, opts, stats);
+}
 int mnmf_run_pnmf(mnmf_ctx* ctx, int k, void* W, void* H, const mnmf_opts* opts, mnmf_stats* stats) {
   if (!ctx || !W || !H) return MNMF_EINVAL;
   return ctx->impl->run_pnmf(k, W, H, opts, stats);

@@ -122,6 +122,12 @@ struct RkArgs {
   int64_t rows;
   int ld;
   T eps;
+  // Batched topic-count sweep (matrix-core kernel, ld <= 32 only): the factor buffers hold several problems side by
+  // side in one padded row; this call works on the problem whose `kcols` columns start at column `coff`.  Logical
+  // column c of the product / update is physical column coff + c of A1, upd, num and out; G1 is the problem's own
+  // ld x ld matrix (zero beyond kcols).  kcols == 0: a plain call (all ld columns, coff 0).
+  int coff = 0;
+  int kcols = 0;
 };
 
 // acc = A1.G1 (+ A2.G2);  PROD: out = acc;  MU: out = upd * (num / (acc + eps));
@@ -303,15 +309,49 @@ __global__ void pad_rows_kernel(const T* __restrict__ in, int64_t rows, int k, i
 }
 
 // rows x ld -> rows x k, entries below thr set to 0 (thr <= 0: plain copy) (nmf_basic.py:86-87).
+// coff: first of the k columns inside the padded row (batched sweep; 0 otherwise).
 template <typename T>
 __global__ void unpad_rows_kernel(const T* __restrict__ in, int64_t rows, int k, int ld, T thr,
-                                  T* __restrict__ out, const int32_t* __restrict__ map = nullptr) {
+                                  T* __restrict__ out, const int32_t* __restrict__ map = nullptr, int coff = 0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * k) return;
   const int64_t r = i / k;
   const int c = (int)(i % k);
-  const T v = in[(map ? (int64_t)map[r] : r) * ld + c];
+  const T v = in[(map ? (int64_t)map[r] : r) * ld + coff + c];
   out[i] = (thr > T(0) && v < thr) ? T(0) : v;
+}
+
+// Batched sweep, boundary only: columns [coff, coff + k) of the padded rows <- a rows x k matrix (transposed = 0) or
+// the transpose of a k x rows matrix (transposed = 1: H as the reference holds it); the other columns are left alone.
+template <typename T>
+__global__ void put_cols_kernel(const T* __restrict__ in, int64_t rows, int k, int ld, int coff, int transposed,
+                                T* __restrict__ out, const int32_t* __restrict__ map) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * k) return;
+  const int64_t r = transposed ? i % rows : i / k;
+  const int c = (int)(transposed ? i / rows : i % k);
+  out[(map ? (int64_t)map[r] : r) * ld + coff + c] = in[i];
+}
+
+// ... and back: a k x rows matrix <- the transpose of columns [coff, coff + k), thresholded (H out).
+template <typename T>
+__global__ void get_cols_t_kernel(const T* __restrict__ in, int64_t rows, int k, int ld, int coff, T thr,
+                                  T* __restrict__ out, const int32_t* __restrict__ map) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * k) return;
+  const int64_t r = i % rows;
+  const int c = (int)(i / rows);
+  const T v = in[(map ? (int64_t)map[r] : r) * ld + coff + c];
+  out[i] = (thr > T(0) && v < thr) ? T(0) : v;
+}
+
+// G (ld x ld) <- the k x k diagonal block of the concatenated Gram `cat` that starts at (coff, coff), zero padded.
+template <typename T>
+__global__ void diag_block_kernel(const T* __restrict__ cat, int ld, int coff, int k, T* __restrict__ G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ld * ld) return;
+  const int r = idx / ld, c = idx % ld;
+  G[idx] = (r < k && c < k) ? cat[(coff + r) * ld + coff + c] : T(0);
 }
 
 // H (k x V row-major) -> Ht (V x ld, zero padded), 32 x 32 tiles through LDS.

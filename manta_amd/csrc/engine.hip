@@ -1313,6 +1313,196 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  // ------------------------------------------------------------------ loop A, several topic counts in one pass over X
+  // The topic-count sweep of the reference (optimization_pipeline.py:105-136, 193-198) calls run_nmf once per candidate k
+  // on the same matrix.  For small k the engine pads every factor row to one 128-byte line (ld = 32 floats), and most
+  // of a gathered line is padding (69 % at k = 10); here n problems with sum(k) <= 32 share that line: their factors sit
+  // side by side in the padded rows, so BOTH SpMMs of an iteration serve all problems in one pass over X (the SpMM works
+  // column by column, a column's sum does not depend on its neighbours).  The dense side runs per problem, on its own
+  // columns in place (RkArgs::coff / kcols) with its own k x k Grams, through the same fused update kernel as a single
+  // run: every number a problem sees is produced by the same operations in the same order as in its own run_nmf, so
+  // each result is bit-identical to the single-k run (tests/test_gpu_sweep.py).  Each problem stops by the reference's
+  // rule on its own norms (nmf_basic.py:52-62): its factors are copied out at that iteration while the others go on.
+  // Not for sharded contexts (the exchange would have to be per problem) and fp32 only; the Python side falls back to
+  // one run_nmf per k otherwise.
+  int run_nmf_sweep(int n, const int32_t* ks, void* const* Ws, void* const* Hs, const mnmf_opts* o, mnmf_stats* stats) override {
+    if constexpr (sizeof(T) != 4) {
+      return fail(MNMF_EINVAL, "run_nmf_sweep: batching is implemented for fp32 contexts");
+    } else {
+      if (n < 1 || n > 32 || !ks || !Ws || !Hs) return fail(MNMF_EINVAL, "run_nmf_sweep: bad arguments");
+      int sum = 0;
+      std::vector<int> off(n);
+      for (int p = 0; p < n; ++p) {
+        if (ks[p] <= 0 || !Ws[p] || !Hs[p]) return fail(MNMF_EINVAL, "run_nmf_sweep: bad problem " + std::to_string(p));
+        off[p] = sum;
+        sum += ks[p];
+      }
+      MNMF_TRY(check_ready(sum));
+      const int ld = ld_of(sum);
+      if (sum > 32 || ld != 32 || !can_fuse(ld))
+        return fail(MNMF_EINVAL, "run_nmf_sweep: the topic counts of one batch must add up to at most 32 (one 128-byte factor row)");
+      if (ctx->sharded()) return fail(MNMF_EINVAL, "run_nmf_sweep: not available on a sharded context");
+      const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 10000;
+      const int fixed = o ? o->fixed_iters : 0;
+      const int every = (o && o->check_every > 0) ? o->check_every : 1;
+      const bool force_check = o && o->force_check;
+      const double thr = (o && o->norm_thresh >= 0) ? o->norm_thresh : 0.005;
+      const double eps = (o && o->eps >= 0) ? o->eps : 1e-10;
+      const double zthr = (o && o->zero_threshold >= 0) ? o->zero_threshold : 1e-5;
+      const bool finalize = !o || o->finalize;
+      const size_t wsz = (size_t)std::max<int64_t>(m, 1) * ld * sizeof(T), hsz = (size_t)V * ld * sizeof(T);
+      const size_t gel = (size_t)ld * ld, gsz = gel * sizeof(T);
+      for (int i = 0; i < 2; ++i) {
+        E_HIP(Wb[i].ensure(wsz));
+        E_HIP(Hb[i].ensure(hsz));
+      }
+      E_HIP(Nw.ensure(wsz));
+      E_HIP(Ex.ensure(hsz + gsz));
+      E_HIP(small.ensure((size_t)(4 * n + 1) * gsz));   // per problem: W^T W, H H^T, dW gram, dH gram; + the concatenated Gram
+      T* Nh = Ex.template as<T>();
+      T* sm = small.template as<T>();
+      auto Gw = [&](int p) { return sm + (size_t)(4 * p) * gel; };
+      auto Gh = [&](int p) { return sm + (size_t)(4 * p + 1) * gel; };
+      auto Gd = [&](int p) { return sm + (size_t)(4 * p + 2) * gel; };   // [dW gram | dH gram]
+      T* Gcat = sm + (size_t)(4 * n) * gel;
+      MNMF_TRY(ensure_prepared());
+      E_HIP(hipMemsetAsync(Wb[0].p, 0, wsz, st()));   // columns beyond sum(k) stay zero
+      E_HIP(hipMemsetAsync(Hb[0].p, 0, hsz, st()));
+      for (int p = 0; p < n; ++p) {
+        if (m > 0) {
+          put_cols_kernel<T><<<(unsigned)cdiv(m * ks[p], 256), 256, 0, st()>>>((const T*)Ws[p], m, ks[p], ld, off[p], 0, Wb[0].template as<T>(), nullptr);
+          E_LAUNCH();
+        }
+        put_cols_kernel<T><<<(unsigned)cdiv(V * ks[p], 256), 256, 0, st()>>>((const T*)Hs[p], V, ks[p], ld, off[p], 1, Hb[0].template as<T>(), vmap());
+        E_LAUNCH();
+      }
+      E_HIP(hipMemcpyAsync(Wb[1].p, Wb[0].p, wsz, hipMemcpyDeviceToDevice, st()));   // the other halves: same zero columns
+      E_HIP(hipMemcpyAsync(Hb[1].p, Hb[0].p, hsz, hipMemcpyDeviceToDevice, st()));
+      std::vector<int> state(n, 0);           // 0 running, 1 stopped by the rule (factors copied out)
+      std::vector<double> wn(n, INFINITY), hn(n, INFINITY);
+      std::vector<int64_t> it_done(n, 0);
+      int cw = 0, ch = 0;
+      int64_t i = 0, done = 0;
+      bool gw_valid = false, pending = false;
+      LoopClock clk;
+      MNMF_TRY(clock_start(clk));
+      std::vector<double> g;
+      MNMF_TRY(pinned((size_t)n * 2 * gel));
+      auto copy_out = [&](int p, const T* Wsrc, const T* Hsrc) -> int {
+        const T t = (T)(finalize ? zthr : -1.0);
+        if (m > 0) {
+          unpad_rows_kernel<T><<<(unsigned)cdiv(m * ks[p], 256), 256, 0, st()>>>(Wsrc, m, ks[p], ld, t, (T*)Ws[p], nullptr, off[p]);   // :86
+          E_LAUNCH();
+        }
+        get_cols_t_kernel<T><<<(unsigned)cdiv(V * ks[p], 256), 256, 0, st()>>>(Hsrc, V, ks[p], ld, off[p], t, (T*)Hs[p], vmap());     // :87
+        E_LAUNCH();
+        return 0;
+      };
+      auto fill = [&](int p, int conv) {
+        if (!stats) return;
+        stats[p].iters = (int32_t)it_done[p];
+        stats[p].converged = conv;
+        stats[p].w_norm = wn[p];
+        stats[p].h_norm = hn[p];
+        stats[p].s_norm = 0;
+      };
+      // norms of the last checked iteration; problems that meet the rule are copied out of the CURRENT halves, which
+      // still hold that iteration's factors (see run_nmf: the next iteration has only written the other halves)
+      auto resolve = [&]() -> int {
+        MNMF_TRY(fetch_end(g));
+        pending = false;
+        for (int p = 0; p < n; ++p) {
+          if (state[p]) continue;
+          wn[p] = spectral_from_gram(g.data() + (size_t)(2 * p) * gel, ld);
+          hn[p] = spectral_from_gram(g.data() + (size_t)(2 * p + 1) * gel, ld);
+          if (!std::isfinite(wn[p]) || !std::isfinite(hn[p]))
+            return fail(MNMF_ENAN, "nmf sweep: non-finite update norm of problem " + std::to_string(p) + " at iteration " + std::to_string(done));
+          if (fixed <= 0 && wn[p] < thr && hn[p] < thr) {
+            state[p] = 1;
+            it_done[p] = done;
+            MNMF_TRY(copy_out(p, Wb[cw].template as<T>(), Hb[ch].template as<T>()));
+            fill(p, 1);
+          }
+        }
+        return 0;
+      };
+      auto all_stopped = [&]() {
+        for (int p = 0; p < n; ++p)
+          if (!state[p]) return false;
+        return true;
+      };
+      while (true) {
+        T* Wc = Wb[cw].template as<T>();
+        T* Wn = Wb[1 - cw].template as<T>();
+        T* Hc = Hb[ch].template as<T>();
+        T* Hn = Hb[1 - ch].template as<T>();
+        const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
+        if (!gw_valid) {  // w.T @ w of every problem: the diagonal blocks of the concatenated Gram      nmf_basic.py:39
+          MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gcat));
+          for (int p = 0; p < n; ++p) {
+            diag_block_kernel<T><<<(unsigned)cdiv((int64_t)gel, 256), 256, 0, st()>>>(Gcat, ld, off[p], ks[p], Gw(p));
+            E_LAUNCH();
+          }
+        }
+        MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                    // every problem's (w.T @ in_mat)^T     :40
+        for (int p = 0; p < n; ++p) {                                      // h update + h @ h.T + |dh| gram        :41-44, :53
+          if (state[p]) continue;
+          RkArgs<float> a{Hc, Gw(p), nullptr, nullptr, Hc, Nh, Hn, V, ld, (float)eps, off[p], ks[p]};
+          MNMF_TRY(rk_fused_nt<1>(RK_MU, a, Gh(p), do_check ? Gd(p) + gel : nullptr));
+        }
+        MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                    // every problem's in_mat @ h.T         :45
+        if (pending) {
+          const int r = resolve();
+          if (r != 0) return r;
+          if (all_stopped()) break;
+        }
+        for (int p = 0; p < n; ++p) {                                      // w update + next w.T @ w + |dw| gram   :46-47, :39, :52
+          if (state[p]) continue;
+          RkArgs<float> a{Wc, Gh(p), nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, (float)eps, off[p], ks[p]};
+          MNMF_TRY(rk_fused_nt<1>(RK_MU, a, Gw(p), do_check ? Gd(p) : nullptr));
+        }
+        gw_valid = true;
+        if (do_check) {
+          MNMF_TRY(fetch_begin((size_t)n * 2 * gel));
+          for (int p = 0; p < n; ++p) MNMF_TRY(fetch_add(Gd(p), 2 * gel));
+          MNMF_TRY(fetch_commit());
+          pending = true;
+        }
+        cw = 1 - cw;
+        ch = 1 - ch;
+        ++done;
+        if (fixed > 0) {
+          if (i + 1 >= fixed) break;
+        } else {
+          if (i >= max_iter) break;                                        // :57
+        }
+        ++i;
+      }
+      if (pending) {
+        const int r = resolve();
+        if (r != 0) return r;
+      }
+      MNMF_TRY(clock_stop(clk, stats));
+      const double ms_total = stats ? stats[0].ms_total : 0.0, ms_kernels = stats ? stats[0].ms_kernels : 0.0;
+      for (int p = 0; p < n; ++p) {
+        if (!state[p]) {   // ran to the iteration cap (or a fixed count): the current factors
+          it_done[p] = done;
+          MNMF_TRY(copy_out(p, Wb[cw].template as<T>(), Hb[ch].template as<T>()));
+          fill(p, 0);
+        }
+        if (stats) {
+          stats[p].ms_total = ms_total;      // of the whole batch
+          stats[p].ms_kernels = ms_kernels;
+          stats[p].bytes_model = 0;
+          stats[p].flops_model = 0;
+          std::memset(stats[p].phase_ms, 0, sizeof(stats[p].phase_ms));
+        }
+      }
+      E_HIP(hipStreamSynchronize(st()));
+      return 0;
+    }
+  }
+
   // ------------------------------------------------------------------ loop B
   int run_pnmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
     MNMF_TRY(check_ready(k));

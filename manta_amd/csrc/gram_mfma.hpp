@@ -321,16 +321,18 @@ void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restric
   const int cl = lane & 31, rh = lane >> 5;
   const int ld = a.ld;
   const unsigned rowb = (unsigned)ld * 4u;
+  const int kc = a.kcols > 0 ? a.kcols : ld;   // columns of this call (batched sweep: one problem's; RkArgs)
+  const unsigned cob = 4u * (unsigned)a.coff;  // ... and where they start inside the padded row, in bytes
   bool cok[NT];
   unsigned goff[NT], eoff[NT];  // byte offsets: G operand (row 8*rh, column), epilogue (row 4*rh, column)
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     const int col = 32 * NT * (int)blockIdx.y + 32 * q + cl;   // blockIdx.y: column group of 32*NT columns (ld > 128)
-    cok[q] = col < ld;
+    cok[q] = col < kc;
     goff[q] = cok[q] ? (unsigned)(8 * rh) * rowb + 4u * col : kPoison;
-    eoff[q] = cok[q] ? (unsigned)(4 * rh) * rowb + 4u * col : kPoison;
+    eoff[q] = cok[q] ? (unsigned)(4 * rh) * rowb + 4u * col + cob : kPoison;
   }
-  const unsigned aoff = (unsigned)cl * rowb + 32u * rh;  // A operand: row cl, 8 floats at column 8*rh
+  const unsigned aoff = (unsigned)cl * rowb + 32u * rh + cob;  // A operand: row cl, 8 floats at column 8*rh
   f32x16 gnew[(FUSE & 1) ? NTRI : 1], gdif[(FUSE & 2) ? NTRI : 1];
   if (FUSE) {
 #pragma unroll

@@ -10,6 +10,7 @@ struct ImplBase {
   virtual int set_matrix(int64_t m, int64_t V, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
                          const void* vals, int on_device) = 0;
   virtual int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
+  virtual int run_nmf_sweep(int n, const int32_t* ks, void* const* W, void* const* H, const mnmf_opts* o, mnmf_stats* st) = 0;
   virtual int run_pnmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
   virtual int run_nmtf(int k, void* W, void* S, void* H, const mnmf_opts* o, mnmf_stats* st) = 0;
   virtual int k_spmm(int transpose, int k, const void* B, void* out) = 0;

@@ -231,6 +231,27 @@ class Engine:
         self._check(self._lib.mnmf_run_nmf(self._h, k, W.data_ptr(), H.data_ptr(), C.byref(o), C.byref(s)))
         return W, H, self._stats(s)
 
+    def run_nmf_sweep(self, W0s, H0s, **kw):
+        """Standard NMF for several topic counts in one pass over X per SpMM (mnmf_run_nmf_sweep): ``W0s[p]`` is
+        m x k_p, ``H0s[p]`` is k_p x V, the k_p of one call add up to at most 32 (fp32).  Returns a list of
+        ``(W, H, stats)``, each bit-identical to ``run_nmf(W0s[p], H0s[p])`` on its own."""
+        n = len(W0s)
+        if n == 0 or n != len(H0s):
+            raise ValueError("W0s and H0s must be equally long, non-empty lists")
+        Ws = [self._dev(w).clone() for w in W0s]
+        Hs = [self._dev(h).clone() for h in H0s]
+        ks = [int(w.shape[1]) for w in Ws]
+        for w, h, k in zip(Ws, Hs, ks):
+            if w.shape != (self.m, k) or h.shape != (k, self.V):
+                raise ValueError(f"W0 {tuple(w.shape)} / H0 {tuple(h.shape)} do not match X {self.m}x{self.V}")
+        ks_c = (C.c_int32 * n)(*ks)
+        wp = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])
+        hp = (C.c_void_p * n)(*[h.data_ptr() for h in Hs])
+        st = (_lib.MnmfStats * n)()
+        o = _opts(**kw)
+        self._check(self._lib.mnmf_run_nmf_sweep(self._h, n, ks_c, wp, hp, C.byref(o), st))
+        return [(Ws[p], Hs[p], self._stats(st[p])) for p in range(n)]
+
     def run_pnmf(self, W0, **kw):
         W = self._dev(W0).clone()
         k = W.shape[1]

@@ -166,6 +166,79 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     return out
 
 
+SWEEP_LINE = 32   # fp32 factor columns that share one padded 128-byte row (mnmf_run_nmf_sweep)
+
+
+def sweep_batches(ks, limit=SWEEP_LINE):
+    """Greedy grouping of topic counts, in the given order, into batches whose counts add up to at most ``limit``;
+    a count above the limit is a batch of its own.  Returns lists of positions into ``ks``."""
+    batches, cur, tot = [], [], 0
+    for i, k in enumerate(ks):
+        if cur and tot + k > limit:
+            batches.append(cur)
+            cur, tot = [], 0
+        cur.append(i)
+        tot += k
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initialization_nndsvd, norm_thresh=0.001,
+                  zero_threshold=0.00001, nmf_method: str = "nmf", *, dtype: Optional[str] = None, device=None,
+                  max_iter: Optional[int] = None, fixed_iters: Optional[int] = None, check_every: int = 1,
+                  starts=None, stats_out: Optional[list] = None) -> list:
+    """``[run_nmf(k, sparse_matrix, ...) for k in topic_counts]`` -- the loop of OptimizationPipeline.run_optimization
+    (optimization_pipeline.py:105-136, 193-198) -- with the matrix uploaded once and, for standard NMF in fp32, the
+    topic counts that fit one padded factor row (sum <= 32) iterated TOGETHER: one pass over X per SpMM serves the
+    whole batch.  Every entry of the returned list equals the single ``run_nmf`` call bit for bit (same start).
+
+    ``starts``: optional list of ``(W0, H0)`` per topic count; otherwise ``init`` is called once per count, in order,
+    as the reference's loop would.  Other methods, fp64 and counts that do not fit a batch run one by one."""
+    ks = [int(k) for k in topic_counts]
+    dtype = dtype or os.environ.get("MANTA_AMD_DTYPE", "fp64")
+    results = [None] * len(ks)
+    stats = [dict() for _ in ks]
+    batched = nmf_method == "nmf" and dtype == "fp32" and all(k > 0 for k in ks)
+    if nmf_method not in ("nmf", "pnmf", "nmtf"):
+        raise ValueError(f"Unknown NMF method: {nmf_method}. Supported methods are: 'nmf', 'pnmf', 'nmtf'")
+    extra = dict(check_every=check_every)
+    if max_iter is not None:
+        extra["max_iter"] = max_iter
+    if fixed_iters:
+        extra["fixed_iters"] = fixed_iters
+    if batched:
+        csc = sparse_matrix.tocsc() if starts is None else None
+        if starts is None:
+            starts = [init(csc, k) for k in ks]                            # nmf_orchestrator.py:109, once per call
+        key = _matrix_key(sparse_matrix)
+        eng = _engine(dtype, device)
+        if key is None or eng._resident_key != key:
+            eng.set_matrix((csc if csc is not None else sparse_matrix).tocsr())
+            eng._resident_key = key
+        for batch in sweep_batches(ks):
+            if len(batch) == 1:
+                i = batch[0]
+                W, H, st = eng.run_nmf(starts[i][0], starts[i][1], norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)
+                outs = [(W, H, st)]
+            else:
+                outs = eng.run_nmf_sweep([starts[i][0] for i in batch], [starts[i][1] for i in batch],
+                                         norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)
+            for i, (W, H, st) in zip(batch, outs):
+                results[i] = {"W": np.ascontiguousarray(eng._host(W)), "H": np.ascontiguousarray(eng._host(H))}
+                stats[i].update(iters=st.iters, converged=st.converged, w_norm=st.w_norm, h_norm=st.h_norm,
+                                ms_total=st.ms_total, batch=[ks[j] for j in batch])
+    else:
+        for i, k in enumerate(ks):
+            kw = {} if starts is None else dict(W0=starts[i][0], H0=starts[i][1])
+            results[i] = run_nmf(k, sparse_matrix, init=init, norm_thresh=norm_thresh, zero_threshold=zero_threshold,
+                                 nmf_method=nmf_method, dtype=dtype, device=device, max_iter=max_iter,
+                                 fixed_iters=fixed_iters, check_every=check_every, stats_out=stats[i], **kw)
+    if stats_out is not None:
+        stats_out[:] = stats
+    return results
+
+
 def install(tfidf: bool = False) -> list:
     """Rebind ``run_nmf`` inside an installed MANTA.  Callers bind the name at import time
     (modeling_pipeline.py:10, optimization_pipeline.py:16), so the attribute is replaced on each

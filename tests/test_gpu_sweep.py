@@ -1,0 +1,113 @@
+"""Batched topic-count sweep (optimization_pipeline.py:105-136, 193-198): several standard-NMF
+problems with sum(k) <= 32 share every pass over X.  The claim under test is the strong one: each problem's result is
+BIT-IDENTICAL to its own single run_nmf call from the same start -- the batch only shares the SpMMs, whose columns are
+independent, and runs the dense side per problem through the same kernels on the problem's own columns."""
+import numpy as np
+import pytest
+
+from oracle import nmf_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().cpu().double().numpy()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from manta_amd.engine import Engine
+
+    e = Engine(dtype="fp32")
+    yield e
+    e.close()
+
+
+def starts_for(X, ks, seed):
+    rng = np.random.RandomState(seed)
+    m, V = X.shape
+    return [(rng.uniform(0, X.max(), (m, k)), rng.uniform(0, X.max(), (k, V))) for k in ks]
+
+
+@pytest.mark.parametrize("ks", [(5, 10, 15), (7, 1, 3, 2), (32,), (16, 16), (10, 20)])
+def test_sweep_fixed_iterations_bit_identical_to_single_runs(eng, golden, ks):
+    g = golden("fixed_B_1000x1200_k10")
+    X = g["X"]
+    eng.set_matrix(X)
+    st = starts_for(X, ks, sum(ks))
+    got = eng.run_nmf_sweep([a for a, _ in st], [b for _, b in st], fixed_iters=25, force_check=True, zero_threshold=1e-5)
+    for (W0, H0), (W, H, s) in zip(st, got):
+        W1, H1, s1 = eng.run_nmf(W0, H0, fixed_iters=25, force_check=True, zero_threshold=1e-5)
+        assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
+        assert s.iters == s1.iters == 25 and s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
+    # and against the CPU oracle within the fp32 tolerance
+    want = oc.basic_nmf(X, st[0][0].copy(), st[0][1].copy(), zero_threshold=1e-5, n_iter=25, check=False)
+    assert np.linalg.norm(host(got[0][0]) - want["W"]) <= 1e-4 * np.linalg.norm(want["W"])
+
+
+def test_sweep_each_problem_stops_at_its_own_iteration(eng, golden):
+    """Under the reference's stopping rule the problems of a batch converge at different iterations; each must return
+    the factors, the iteration count and the norms of its own single run."""
+    g = golden("converged_D_600x500_k6_nmf")
+    X = g["X"]
+    eng.set_matrix(X)
+    ks = (5, 10, 15)
+    st = starts_for(X, ks, 77)
+    got = eng.run_nmf_sweep([a for a, _ in st], [b for _, b in st], norm_thresh=0.005, zero_threshold=1e-5)
+    iters = []
+    for (W0, H0), (W, H, s) in zip(st, got):
+        W1, H1, s1 = eng.run_nmf(W0, H0, norm_thresh=0.005, zero_threshold=1e-5)
+        assert s.converged and s1.converged and s.iters == s1.iters
+        assert s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
+        assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
+        iters.append(s.iters)
+    assert len(set(iters)) > 1, iters     # otherwise the test does not exercise the staggered stop
+    # an iteration cap below every stopping point: nobody converges, everybody returns the capped factors
+    got = eng.run_nmf_sweep([a for a, _ in st], [b for _, b in st], norm_thresh=0.005, max_iter=3)
+    for (W0, H0), (W, H, s) in zip(st, got):
+        W1, H1, s1 = eng.run_nmf(W0, H0, norm_thresh=0.005, max_iter=3)
+        assert not s.converged and s.iters == s1.iters == 4
+        assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
+
+
+def test_sweep_refuses_what_it_cannot_batch(eng, golden):
+    from manta_amd.engine import Engine, MnmfError
+
+    g = golden("fixed_A_300x200_k5")
+    eng.set_matrix(g["X"])
+    st = starts_for(g["X"], (20, 13), 1)
+    with pytest.raises(MnmfError) as ei:
+        eng.run_nmf_sweep([a for a, _ in st], [b for _, b in st], fixed_iters=2)
+    assert ei.value.code == -1 and "at most 32" in str(ei.value)
+    e64 = Engine(dtype="fp64")
+    try:
+        e64.set_matrix(g["X"])
+        st = starts_for(g["X"], (5, 5), 2)
+        with pytest.raises(MnmfError):
+            e64.run_nmf_sweep([a for a, _ in st], [b for _, b in st], fixed_iters=2)
+    finally:
+        e64.close()
+
+
+def test_run_nmf_sweep_drop_in_groups_and_falls_back(golden):
+    """manta_amd.run_nmf_sweep == [run_nmf(k, X) for k in ks] (same starts), whatever the grouping: 5+10+15 go together,
+    20 alone; pnmf and fp64 run one by one."""
+    import manta_amd
+    from manta_amd.nmf import sweep_batches
+
+    assert sweep_batches([5, 10, 15, 20, 40, 3]) == [[0, 1, 2], [3], [4], [5]]
+    g = golden("converged_D_600x500_k6_nmf")
+    X = g["X"]
+    ks = [5, 10, 15, 20]
+    st = starts_for(X, ks, 5)
+    stats = []
+    got = manta_amd.run_nmf_sweep(X, ks, norm_thresh=0.005, dtype="fp32", starts=st, stats_out=stats)
+    assert [s["batch"] for s in stats] == [[5, 10, 15]] * 3 + [[20]]
+    for k, (W0, H0), out, s in zip(ks, st, got, stats):
+        one = {}
+        want = manta_amd.run_nmf(k, X, norm_thresh=0.005, dtype="fp32", W0=W0, H0=H0, stats_out=one)
+        assert sorted(out) == ["H", "W"] and out["W"].dtype == np.float64
+        assert np.array_equal(out["W"], want["W"]) and np.array_equal(out["H"], want["H"])
+        assert s["iters"] == one["iters"]
+    got = manta_amd.run_nmf_sweep(X, [4, 6], norm_thresh=0.005, nmf_method="pnmf", dtype="fp64", starts=starts_for(X, [4, 6], 6))
+    assert [o["W"].shape[1] for o in got] == [4, 6]
