@@ -16,6 +16,7 @@
 #include "eig.hpp"
 #include "gram_mfma.hpp"
 #include "histogram.hpp"
+#include "rk_mfma_f64.hpp"
 #include "sparse_prep.hpp"
 #include "spmm.hpp"
 #include "topk.hpp"
@@ -77,6 +78,7 @@ struct Tune {
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
+  int mfma_f64 = 1;                   // fp64 update + fused Grams on the matrix cores (k <= 64)
   int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
   Tune() {
@@ -111,6 +113,7 @@ struct Tune {
     xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     rs_ag = (int)geti("MNMF_RS_AG", rs_ag);
+    mfma_f64 = (int)geti("MNMF_MFMA_F64", mfma_f64);
   }
 };
 
@@ -875,6 +878,8 @@ class Engine : public ImplBase {
     RkArgs<T> a{A1, G1, A2, G2, upd, num, out, rows, ld, (T)eps};
     if constexpr (sizeof(T) == 4) {
       if (tune.mfma_rk && ld <= 256 && (ld <= 32 || ld % 16 == 0)) return rk_mfma(mode, a);
+    } else {
+      if (can_fuse(ld)) return rk64(mode, a, nullptr, nullptr);
     }
     dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(ld, 64));
     if (mode == RK_PROD) dense_rk_kernel<T, RK_PROD><<<grid, 256, 0, st()>>>(a);
@@ -931,7 +936,59 @@ class Engine : public ImplBase {
     return rk_fused_launch<NT, RK_MU_SQRT, 2>(a, gram_new, gram_diff);
   }
   bool can_fuse(int ld) const {
-    return sizeof(T) == 4 && tune.mfma_rk && tune.mfma_gram && tune.fuse_grams && (ld <= 32 || ld == 48 || ld == 64);
+    if (sizeof(T) == 8) return tune.mfma_rk && tune.mfma_f64 && (ld == 16 || ld == 32 || ld == 48 || ld == 64);
+    return tune.mfma_rk && tune.mfma_gram && tune.fuse_grams && (ld <= 32 || ld == 48 || ld == 64);
+  }
+
+  // fp64 on the matrix cores (rk_mfma_f64.hpp): product / update, with the Grams of the new factor and of |new - old|
+  // in the same pass when asked for
+  template <int NT, int MODE>
+  int rk64_launch(const RkArgs<double>& a, double* gram_new, double* gram_diff) {
+    const int fuse = MODE == RK_PROD ? 0 : (gram_new ? 1 : 0) | (gram_diff ? 2 : 0);
+    const int64_t elems = (int64_t)a.ld * a.ld;
+    const int64_t n_tiles = cdiv(a.rows, 16);
+    const int64_t nb = std::max<int64_t>(1, std::min<int64_t>(cdiv(n_tiles, 4), 2 * (int64_t)n_cus));
+    double* s_new = nullptr;
+    double* s_dif = nullptr;
+    if (fuse) {
+      E_HIP(slab.ensure((size_t)(2 * nb * elems) * sizeof(double)));
+      s_new = slab.template as<double>();
+      s_dif = s_new + nb * elems;
+    }
+    if constexpr (MODE == RK_PROD) {
+      dense_rk_mfma_f64_kernel<NT, MODE, 0><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    } else {
+      if (fuse == 3) dense_rk_mfma_f64_kernel<NT, MODE, 3><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, s_new, s_dif);
+      else if (fuse == 1) dense_rk_mfma_f64_kernel<NT, MODE, 1><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, s_new, s_dif);
+      else if (fuse == 2) dense_rk_mfma_f64_kernel<NT, MODE, 2><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, s_new, s_dif);
+      else dense_rk_mfma_f64_kernel<NT, MODE, 0><<<(unsigned)nb, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    }
+    E_LAUNCH();
+    if (fuse == 3) {
+      slab_reduce_kernel<double><<<dim3((unsigned)cdiv(elems, 16), 2), 256, 0, st()>>>(s_new, nb, elems, gram_new, s_dif, gram_diff);
+      E_LAUNCH();
+    } else if (fuse == 1) {
+      slab_reduce_kernel<double><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(s_new, nb, elems, gram_new);
+      E_LAUNCH();
+    } else if (fuse == 2) {
+      slab_reduce_kernel<double><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(s_dif, nb, elems, gram_diff);
+      E_LAUNCH();
+    }
+    return 0;
+  }
+  template <int NT>
+  int rk64_nt(int mode, const RkArgs<double>& a, double* gram_new, double* gram_diff) {
+    if (mode == RK_PROD) return rk64_launch<NT, RK_PROD>(a, nullptr, nullptr);
+    if (mode == RK_MU) return rk64_launch<NT, RK_MU>(a, gram_new, gram_diff);
+    return rk64_launch<NT, RK_MU_SQRT>(a, gram_new, gram_diff);
+  }
+  int rk64(int mode, const RkArgs<double>& a, double* gram_new, double* gram_diff) {
+    switch (a.ld / 16) {
+      case 1: return rk64_nt<1>(mode, a, gram_new, gram_diff);
+      case 2: return rk64_nt<2>(mode, a, gram_new, gram_diff);
+      case 3: return rk64_nt<3>(mode, a, gram_new, gram_diff);
+      default: return rk64_nt<4>(mode, a, gram_new, gram_diff);
+    }
   }
 
   // rk() followed by gram(out) -> gram_new and gram(|out - upd|) -> gram_diff (either may be null); one pass
@@ -944,6 +1001,11 @@ class Engine : public ImplBase {
       if (can_fuse(ld) && rows > 0 && mode != RK_PROD) {
         RkArgs<float> a{A1, G1, A2, G2, upd, num, out, rows, ld, (float)eps};
         return ld <= 32 ? rk_fused_nt<1>(mode, a, gram_new, gram_diff) : rk_fused_nt<2>(mode, a, gram_new, gram_diff);
+      }
+    } else {
+      if (can_fuse(ld) && rows > 0 && mode != RK_PROD) {
+        RkArgs<double> a{A1, G1, A2, G2, upd, num, out, rows, ld, (double)eps};
+        return rk64(mode, a, gram_new, gram_diff);
       }
     }
     MNMF_TRY(rk(mode, A1, G1, A2, G2, upd, num, out, rows, ld, eps));
