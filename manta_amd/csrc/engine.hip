@@ -78,6 +78,7 @@ struct Tune {
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
+  int rk_one_pass = 0;                // (measured 4 % slower at the configs[4] shard: the kernel is matrix-core bound) fp32 update with 128 < k <= 256: all column tiles of a row tile in one wave
   int mfma_f64 = 1;                   // fp64 update + fused Grams on the matrix cores (k <= 64)
   int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
@@ -114,6 +115,7 @@ struct Tune {
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     rs_ag = (int)geti("MNMF_RS_AG", rs_ag);
     mfma_f64 = (int)geti("MNMF_MFMA_F64", mfma_f64);
+    rk_one_pass = (int)geti("MNMF_RK_ONE_PASS", rk_one_pass);
   }
 };
 
@@ -1019,8 +1021,20 @@ class Engine : public ImplBase {
       case 1: return rk_mfma_nt<1>(mode, a);
       case 2: return rk_mfma_nt<2>(mode, a);
       case 3: return rk_mfma_nt<3>(mode, a);
-      default: return rk_mfma_nt<4>(mode, a);   // ld > 128: column groups of 128 (grid.y), two waves per SIMD each
+      case 4: return rk_mfma_nt<4>(mode, a);
     }
+    // ld > 128.  One pass: a wave keeps all 5..8 column tiles of its 32 rows (80..128 accumulator registers), so the
+    // row tile is read once and every operand pair feeds 5..8 MFMAs; or (MNMF_RK_ONE_PASS=0) column groups of 128
+    // (grid.y), which read the row tile once per group.
+    if (tune.rk_one_pass) {
+      switch ((a.ld + 31) / 32) {
+        case 5: return rk_mfma_nt<5>(mode, a);
+        case 6: return rk_mfma_nt<6>(mode, a);
+        case 7: return rk_mfma_nt<7>(mode, a);
+        default: return rk_mfma_nt<8>(mode, a);
+      }
+    }
+    return rk_mfma_nt<4>(mode, a);
   }
 
   int kxk(const T* A, const T* B, T* C, int ld, int ta, int tb) {
