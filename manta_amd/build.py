@@ -20,7 +20,7 @@ UNITS = {
     "tfidf.o": ("tfidf.hip", [], ["ctx.hpp", "common.hpp", "histogram.hpp"]),
 }
 HEADER = os.path.join(HERE, "..", "include", "mnmf.h")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + os.environ.get("MNMF_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -28,6 +28,12 @@
 #ifndef MNMF_TILE_CH
 #define MNMF_TILE_CH 32   // nnz per stream chunk in the TILE mode (prefetch distance)
 #endif
+#ifndef MNMF_HOT_EPL
+#define MNMF_HOT_EPL 1    // chunk length of the HOT / PLAIN modes in units of max(16, LPR) nnz
+#endif
+#ifndef MNMF_PLAIN_EPL
+#define MNMF_PLAIN_EPL 1
+#endif
 
 namespace mnmf {
 
@@ -85,7 +91,8 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
   constexpr int NG = kWave / LPR;
   // steps per chunk.  The next chunk of (index, value) is fetched while this one is processed; a step of the TILE
   // mode is an LDS read (tens of cycles), so its chunks are long enough to cover a trip to memory.
-  constexpr int CH = (MODE == SPMM_TILE) ? LPR * (MNMF_TILE_CH / LPR > 8 ? 8 : (MNMF_TILE_CH / LPR < 1 ? 1 : MNMF_TILE_CH / LPR)) : (LPR < 16 ? 16 : LPR);
+  constexpr int CH = (MODE == SPMM_TILE) ? LPR * (MNMF_TILE_CH / LPR > 8 ? 8 : (MNMF_TILE_CH / LPR < 1 ? 1 : MNMF_TILE_CH / LPR))
+                                         : (LPR < 16 ? 16 : LPR) * (MODE == SPMM_HOT ? MNMF_HOT_EPL : MNMF_PLAIN_EPL);
   constexpr int EPL = CH / LPR;            // chunk elements held per lane
   constexpr int U = VPL == 2 ? 4 : 8;      // gathers in flight per batch
   static_assert(CH % U == 0, "U must divide CH");
