@@ -78,6 +78,12 @@ struct Tune {
   int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
   int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
+  int sweep = 0;                      // X^T.W: rare words through the synchronised sweep (0 off: measured 1.6 % slower at C2; 1 when the shape suits it; 2 always: tests)
+  int64_t sweep_lds_bytes = 150 << 10; // LDS for the accumulator rows of one partition
+  int64_t sweep_win_bytes = 2 << 20;  // bytes of W rows per document window (two windows should fit an XCD's L2)
+  int sweep_min_touch_pct = 100;      // use it only if a document is gathered at least this often (percent) per XCD: below, no reuse
+  int64_t sweep_max_df = 0;           // words with up to this many nnz (at least the uncut ones) go to the sweep
+  int sweep_order = 1;                // 0: sweep first, beside the blocked stream; 1: tile || blocked, then the sweep alone; 2: blocked || tile after, sweep last
   int rk_one_pass = 0;                // (measured 4 % slower at the configs[4] shard: the kernel is matrix-core bound) fp32 update with 128 < k <= 256: all column tiles of a row tile in one wave
   int mfma_f64 = 1;                   // fp64 update + fused Grams on the matrix cores (k <= 64)
   int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
@@ -116,6 +122,12 @@ struct Tune {
     rs_ag = (int)geti("MNMF_RS_AG", rs_ag);
     mfma_f64 = (int)geti("MNMF_MFMA_F64", mfma_f64);
     rk_one_pass = (int)geti("MNMF_RK_ONE_PASS", rk_one_pass);
+    sweep = (int)geti("MNMF_SWEEP", sweep);
+    sweep_order = (int)geti("MNMF_SWEEP_ORDER", sweep_order);
+    sweep_max_df = geti("MNMF_SWEEP_MAX_DF", sweep_max_df);
+    sweep_lds_bytes = geti("MNMF_SWEEP_LDS_BYTES", sweep_lds_bytes);
+    sweep_win_bytes = geti("MNMF_SWEEP_WIN_BYTES", sweep_win_bytes);
+    sweep_min_touch_pct = (int)geti("MNMF_SWEEP_MIN_TOUCH_PCT", sweep_min_touch_pct);
   }
 };
 
@@ -165,6 +177,16 @@ struct StreamMat {
   DevBuf seg_start, seg_len, seg_info, dest, empty_rows, fix_row, fix_first, fix_count, carry;
 };
 
+// the sweep stream of X^T (rare words; spmm.hpp: spmm_sweep_kernel)
+struct SweepMat {
+  int64_t nnz = 0;
+  int n_windows = 0, rpp = 0, P = 0, win_shift = 0;
+  int ngw = 0;                  // segments per cell the segment table was built for
+  size_t req_row_bytes = 0;     // what ensure_xt was asked for (0: no sweep wanted)
+  uint32_t base = 0;            // first sweep key
+  DevBuf docs, lrows, vals, words, keys, cell_start, seg;
+};
+
 inline int pow2_ceil(int x) {
   int p = 1;
   while (p < x) p <<= 1;
@@ -191,6 +213,7 @@ class Engine : public ImplBase {
   int64_t m = 0, V = 0, nnz = 0;
   bool have_matrix = false;
   StreamMat<T> X, Xt, Xth;   // X; X^T blocked stream; X^T tile stream of the most frequent words
+  SweepMat Xs;               // X^T sweep stream of the rare words
   std::vector<int64_t> h_rowptr;
   DevBuf d_rowptr;
   // vocabulary renumbering by descending document frequency (identical on every rank)
@@ -269,6 +292,7 @@ class Engine : public ImplBase {
     X = StreamMat<T>();
     Xt = StreamMat<T>();
     Xth = StreamMat<T>();
+    Xs = SweepMat();
     prepared = false;
     renumbered = false;
     X.rows = m;
@@ -403,14 +427,18 @@ class Engine : public ImplBase {
 
   // Build X^T in processing order (see sparse_prep.hpp): the n_hot most frequent words as a tile stream (tiles of
   // tile_rows documents, Xth), the rest blocked by document blocks of 2^bs rows (Xt).  n_hot == 0: everything in Xt.
-  int ensure_xt(int bs, int n_hot, int tile_rows) {
+  // sweep_row_bytes > 0: the rare words go to the sweep stream if their accumulators (that many LDS bytes per word) fit
+  // a partition's LDS budget and the documents are gathered often enough per XCD for the shared window to pay
+  int ensure_xt(int bs, int n_hot, int tile_rows, size_t sweep_row_bytes = 0) {
     if (nnz == 0) return 0;
     if (n_hot <= 0 || tile_rows <= 0) n_hot = 0, tile_rows = 1;
     const uint32_t n_tiles = n_hot > 0 ? (uint32_t)cdiv(m, tile_rows) : 0;
     if ((uint64_t)n_tiles * (uint64_t)n_hot >= ((uint64_t)1 << 31)) n_hot = 0;
     const uint32_t hot_span = n_hot > 0 ? n_tiles * (uint32_t)n_hot : 0u;
     while ((uint64_t)hot_span + (uint64_t)(cdiv(m, (int64_t)1 << bs) + 1) * (uint64_t)V >= ((uint64_t)1 << 32)) ++bs;
-    if (Xt.built && Xt.block_shift == bs && Xth.n_hot == n_hot && (n_hot == 0 || Xth.tile_rows == tile_rows)) return 0;
+    if (Xt.built && Xt.block_shift == bs && Xth.n_hot == n_hot && (n_hot == 0 || Xth.tile_rows == tile_rows) &&
+        Xs.req_row_bytes == sweep_row_bytes)
+      return 0;
     const uint32_t n_blocks = (uint32_t)cdiv(m, (int64_t)1 << bs);
     const size_t n = (size_t)nnz;
     const int TB = 256;
@@ -447,14 +475,78 @@ class Engine : public ImplBase {
     E_HIP(Xth.vals.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * sizeof(T)));
     // a word is cut at document-block boundaries only if its pieces stay long enough to pay for their carry slots
     const int32_t long_df = (int32_t)std::min<int64_t>(std::max<int64_t>(tune.xt_long_floor, (int64_t)tune.xt_min_piece * n_blocks), 1 << 30);
+    // ---- sweep stream of the rare words (not cut at document blocks: df <= long_df)
+    Xs = SweepMat();
+    Xs.req_row_bytes = sweep_row_bytes;
+    SweepMap sw{nullptr, 0, 1, 0, 0};
+    DevBuf rare, rare_df, rare_idx;
+    int64_t n_sweep = 0;
+    if (sweep_row_bytes > 0 && tune.sweep > 0) {
+      E_HIP(rare.ensure((size_t)V * 4));
+      E_HIP(rare_df.ensure((size_t)V * 4));
+      E_HIP(rare_idx.ensure((size_t)V * 4));
+      const int32_t sweep_df = (int32_t)std::min<int64_t>(std::max<int64_t>(long_df, tune.sweep_max_df), 1 << 30);
+      rare_mark_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(df.template as<int32_t>(), V, (uint32_t)n_hot, sweep_df,
+                                                               rare.template as<int32_t>(), rare_df.template as<int32_t>());
+      E_LAUNCH();
+      int32_t h2[2] = {0, 0};
+      for (int which = 0; which < 2; ++which) {   // number of rare words, and their nnz
+        const int32_t* src = which == 0 ? rare.template as<int32_t>() : rare_df.template as<int32_t>();
+        size_t bytes = 0;
+        E_HIP(rocprim::reduce(nullptr, bytes, src, cnt.template as<int32_t>(), 0, (size_t)V, rocprim::plus<int32_t>(), st()));
+        E_HIP(tmp.ensure(bytes));
+        E_HIP(rocprim::reduce(tmp.p, bytes, src, cnt.template as<int32_t>(), 0, (size_t)V, rocprim::plus<int32_t>(), st()));
+        E_HIP(hipMemcpyAsync(&h2[which], cnt.p, 4, hipMemcpyDeviceToHost, st()));
+        E_HIP(hipStreamSynchronize(st()));
+      }
+      const int64_t n_rare = h2[0], rare_nnz = h2[1];
+      const int P = n_cus;
+      const int64_t rpp = std::max<int64_t>(1, cdiv(n_rare, P));
+      int ws = 8;   // window: about sweep_win_bytes of table rows (ld * sizeof(T) bytes each = sweep_row_bytes less the padding)
+      while (ws < 24 && ((int64_t)2 << ws) * (int64_t)sweep_row_bytes <= tune.sweep_win_bytes) ++ws;
+      const int64_t n_win = cdiv(m, (int64_t)1 << ws);
+      const uint64_t sbase = (uint64_t)hot_span + (uint64_t)(n_blocks + 1) * (uint64_t)V;
+      const bool fits = n_rare > 0 && (uint64_t)rpp * sweep_row_bytes <= (uint64_t)tune.sweep_lds_bytes &&
+                        sbase + (uint64_t)n_win * P * (uint64_t)rpp < ((uint64_t)1 << 32) && rare_nnz < ((int64_t)1 << 31) &&
+                        m < ((int64_t)1 << 24) && (uint64_t)m * sweep_row_bytes < ((uint64_t)1 << 32) &&
+                        n_win * P * 64 < ((int64_t)1 << 30);
+      // a document's row is fetched from the fabric once per XCD and sweep; it pays when the XCD then uses it again
+      const bool pays = rare_nnz * 100 >= (int64_t)tune.sweep_min_touch_pct * 8 * m && nnz >= tune.hot_min_nnz;
+      if (fits && (pays || tune.sweep >= 2)) {
+        size_t bytes = 0;
+        E_HIP(rocprim::exclusive_scan(nullptr, bytes, rare.template as<int32_t>(), rare_idx.template as<int32_t>(), 0, (size_t)V,
+                                      rocprim::plus<int32_t>(), st()));
+        E_HIP(tmp.ensure(bytes));
+        E_HIP(rocprim::exclusive_scan(tmp.p, bytes, rare.template as<int32_t>(), rare_idx.template as<int32_t>(), 0, (size_t)V,
+                                      rocprim::plus<int32_t>(), st()));
+        E_HIP(Xs.words.ensure((size_t)rpp * P * 4));
+        E_HIP(hipMemsetAsync(Xs.words.p, 0xFF, (size_t)rpp * P * 4, st()));
+        rare_place_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(rare.template as<int32_t>(), rare_idx.template as<int32_t>(), V,
+                                                                  (uint32_t)P, Xs.words.template as<int32_t>());
+        E_LAUNCH();
+        n_sweep = rare_nnz;
+        Xs.nnz = rare_nnz;
+        Xs.P = P;
+        Xs.rpp = (int)rpp;
+        Xs.win_shift = ws;
+        Xs.n_windows = (int)n_win;
+        Xs.base = (uint32_t)sbase;
+        sw = SweepMap{rare_idx.template as<int32_t>(), (uint32_t)P, (uint32_t)rpp, (uint32_t)ws, (uint32_t)sbase};
+        E_HIP(Xs.docs.ensure((size_t)n_sweep * 4));
+        E_HIP(Xs.lrows.ensure((size_t)n_sweep * 4));
+        E_HIP(Xs.vals.ensure((size_t)n_sweep * sizeof(T)));
+        E_HIP(Xs.keys.ensure((size_t)n_sweep * 4));
+      }
+    }
     transpose_key_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(X.cols.template as<uint32_t>(), rowid.template as<uint32_t>(),
                                                                    df.template as<int32_t>(), nnz, V, bs, n_blocks,
                                                                    long_df, (uint32_t)n_hot, (uint32_t)tile_rows,
-                                                                   hot_span, key.template as<uint32_t>());
+                                                                   hot_span, sw, key.template as<uint32_t>());
     E_LAUNCH();
     {  // stable sort by key: documents stay ascending inside a piece
       int bits = 1;
-      while (((int64_t)1 << bits) < (int64_t)hot_span + ((int64_t)n_blocks + 1) * V) ++bits;
+      const int64_t key_end = (int64_t)hot_span + ((int64_t)n_blocks + 1) * V + (n_sweep > 0 ? (int64_t)Xs.n_windows * Xs.P * Xs.rpp : 0);
+      while (((int64_t)1 << bits) < key_end) ++bits;
       size_t bytes = 0;
       E_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.template as<uint32_t>(), keys_out.template as<uint32_t>(),
                                       iota.template as<uint32_t>(), perm.template as<uint32_t>(), n, 0u, (unsigned)bits, st()));
@@ -464,12 +556,34 @@ class Engine : public ImplBase {
     }
     gather_transposed_kernel<T><<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(
         perm.template as<uint32_t>(), rowid.template as<uint32_t>(), X.vals.template as<T>(), nnz, n_hot_nnz, (uint32_t)tile_rows,
-        Xth.cols.template as<uint32_t>(), Xth.vals.template as<T>(), Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>());
+        Xth.cols.template as<uint32_t>(), Xth.vals.template as<T>(), Xt.cols.template as<uint32_t>(), Xt.vals.template as<T>(),
+        n_sweep, keys_out.template as<uint32_t>(), Xs.base, (uint32_t)std::max(Xs.rpp, 1), Xs.docs.template as<uint32_t>(),
+        Xs.lrows.template as<uint32_t>(), Xs.vals.template as<T>());
     E_LAUNCH();
+    if (n_sweep > 0) {  // the sorted keys of the sweep stream stay: the segment table is cut from them (ensure_sweep_segments)
+      E_HIP(hipMemcpyAsync(Xs.keys.p, keys_out.template as<uint32_t>() + (nnz - n_sweep), (size_t)n_sweep * 4, hipMemcpyDeviceToDevice, st()));
+      const int64_t n_cells = (int64_t)Xs.n_windows * Xs.P;
+      E_HIP(Xs.cell_start.ensure((size_t)(n_cells + 1) * 4));
+      sweep_cells_kernel<<<(unsigned)cdiv(n_cells + 1, TB), TB, 0, st()>>>(Xs.keys.template as<uint32_t>(), n_sweep, Xs.base,
+                                                                          (uint32_t)Xs.rpp, n_cells, Xs.cell_start.template as<int32_t>());
+      E_LAUNCH();
+    }
+    // From here on only the tile and the blocked stream: pieces are cut on the host from their part of the sorted keys.
+    // (Names below keep `nnz` for the length of that part.)
+    return finish_xt(bs, n_hot, tile_rows, n_tiles, hot_span, n_blocks, n_hot_nnz, nnz - n_sweep, keys_out, iota, flag, cnt, tmp, pkey);
+  }
+
+  // second half of ensure_xt: `nnz` here is the length of the tile + blocked part of the sorted keys
+  int finish_xt(int bs, int n_hot, int tile_rows, uint32_t n_tiles, uint32_t hot_span, uint32_t n_blocks, int64_t n_hot_nnz,
+                int64_t nnz, DevBuf& keys_out, DevBuf& iota, DevBuf& flag, DevBuf& cnt, DevBuf& tmp, DevBuf& pkey) {
+    const int TB = 256;
+    const size_t n = (size_t)nnz;
     // piece starts = positions where the key changes
-    E_HIP(flag.ensure(n));
-    piece_flag_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), nnz, flag.template as<uint8_t>());
-    E_LAUNCH();
+    E_HIP(flag.ensure(std::max<size_t>(n, 1)));
+    if (nnz > 0) {
+      piece_flag_kernel<<<(unsigned)cdiv(nnz, TB), TB, 0, st()>>>(keys_out.template as<uint32_t>(), nnz, flag.template as<uint8_t>());
+      E_LAUNCH();
+    }
     uint32_t* d_pos = iota.template as<uint32_t>();  // iota is dead after the sort: reuse as the position list
     {
       size_t bytes = 0;
@@ -690,7 +804,42 @@ class Engine : public ImplBase {
         const int64_t min_rows = tune.tile_min_rows, min_tiles = (int64_t)tune.tile_min_tiles_pct * n_cus / 100;
         if (tile_rows < min_rows || n_hot < 8 || cdiv(m, tile_rows) < std::max<int64_t>(min_tiles, 4)) n_hot = 0;
       }
-      MNMF_TRY(ensure_xt(bs, n_hot, tile_rows));
+      // rare words: synchronised sweep with LDS accumulators (one vector per lane only)
+      const size_t sweep_rb = (vmap() && tune.sweep > 0 && vpl == 1 && !tune.force_wide) ? (size_t)lds_ld * sizeof(T) : 0;
+      MNMF_TRY(ensure_xt(bs, n_hot, tile_rows, sweep_rb));
+    }
+    if (&M == &Xt && Xs.nnz > 0) {
+      // Three streams of X^T: sweep (rare words; LDS accumulators, needs its workgroups resident together and in step,
+      // so it is launched first, on the idle GPU), blocked (the words in between; no LDS, small workgroups that fill the
+      // other half of every CU: on the side stream), tile (the most frequent words; most of a CU's LDS: behind the sweep).
+      // They write disjoint rows of `out`; rows without nnz are zeroed before the fork.
+      MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 1));
+      if (Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
+      const bool fork = tune.xt_overlap && Xt.nnz > 0;
+      if (fork) {
+        if (!side_stream) {
+          E_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+          E_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+          E_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        E_HIP(hipEventRecord(ev_fork, ctx->stream));
+        E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+      }
+      if (tune.sweep_order == 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr));
+      if (tune.sweep_order == 1 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      if (Xt.nnz > 0) {
+        if (fork) st_override = side_stream;
+        const int r = spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2);
+        st_override = nullptr;
+        MNMF_TRY(r);
+      }
+      if (tune.sweep_order != 1 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      if (fork) {
+        E_HIP(hipEventRecord(ev_join, side_stream));
+        E_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
+      }
+      if (tune.sweep_order != 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr));
+      return 0;
     }
     if (&M == &Xt && Xth.nnz > 0 && tune.xt_overlap) {
       // The blocked stream is bound by the vector-memory path and the fabric, the tile stream by LDS and VALU
@@ -754,6 +903,37 @@ class Engine : public ImplBase {
       if (hot < 16) hot = 0;
     }
     return spmm_dispatch(M, B, ld, ld, 0, out, hot, lds_ld, vpl, lpr);
+  }
+
+  template <int LPR>
+  int sweep_launch(const T* B, int ld, T* out, int lds_ld) {
+    constexpr int NGW = 16 * (kWave / LPR);
+    const int64_t n_cells = (int64_t)Xs.n_windows * Xs.P;
+    if (Xs.ngw != NGW) {
+      E_HIP(Xs.seg.ensure((size_t)(n_cells * NGW + 1) * 4));
+      sweep_segs_kernel<<<(unsigned)cdiv(n_cells * NGW + 1, 256), 256, 0, st()>>>(Xs.keys.template as<uint32_t>(), Xs.cell_start.template as<int32_t>(),
+                                                                                 n_cells, NGW, Xs.seg.template as<int32_t>());
+      E_LAUNCH();
+      Xs.ngw = NGW;
+    }
+    SweepArgs<T> a{Xs.seg.template as<int32_t>(), Xs.n_windows, Xs.docs.template as<uint32_t>(), Xs.lrows.template as<uint32_t>(),
+                   Xs.vals.template as<T>(), B, ld, lds_ld, Xs.rpp, (uint32_t)((size_t)m * ld * sizeof(T)),
+                   Xs.words.template as<int32_t>(), out};
+    auto kern = spmm_sweep_kernel<T, LPR, 1>;
+    const size_t lds_bytes = (size_t)Xs.rpp * lds_ld * sizeof(T) + 64;
+    E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    kern<<<(unsigned)Xs.P, 1024, lds_bytes, st()>>>(a);
+    E_LAUNCH();
+    return 0;
+  }
+  int sweep_dispatch(const T* B, int ld, T* out, int lds_ld, int lpr) {
+    switch (lpr) {
+      case 4: return sweep_launch<4>(B, ld, out, lds_ld);
+      case 8: return sweep_launch<8>(B, ld, out, lds_ld);
+      case 16: return sweep_launch<16>(B, ld, out, lds_ld);
+      case 32: return sweep_launch<32>(B, ld, out, lds_ld);
+      default: return sweep_launch<64>(B, ld, out, lds_ld);
+    }
   }
 
   int spmm_dispatch(StreamMat<T>& M, const T* B, int ld, int nc, int c0, T* out, int hot, int lds_ld, int vpl, int lpr) {

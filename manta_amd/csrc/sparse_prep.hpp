@@ -243,14 +243,31 @@ static __global__ void expand_rowids_kernel(const int64_t* __restrict__ rp, int6
   iota[p] = (uint32_t)p;
 }
 
+// Sweep layout of the rare words (spmm.hpp, spmm_sweep_kernel): which words, where their accumulators live.
+struct SweepMap {
+  const int32_t* rare_idx;  // [V] dense index of a rare word among the rare words, -1 for the others; null: no sweep
+  uint32_t P;               // partitions (= workgroups of the sweep kernel)
+  uint32_t rpp;             // accumulator rows per partition
+  uint32_t win_shift;       // log2(documents per window)
+  uint32_t base;            // first key of the sweep stream
+};
+// dense index i of a rare word -> (partition, accumulator row): the rare words are dealt to the partitions in snake
+// order (0 .. P-1, P-1 .. 0, ...): their ids are sorted by document frequency, so the partitions' nnz come out even
+__host__ __device__ inline void sweep_place(uint32_t i, uint32_t P, uint32_t& part, uint32_t& row) {
+  row = i / P;
+  const uint32_t pos = i - row * P;
+  part = (row & 1u) ? P - 1u - pos : pos;
+}
+
 // Sort key of nnz p for the transposed streams.  Words below n_hot (the most frequent ones after the engine's
 // renumbering) go to the TILE stream: key = tile * n_hot + word with tile = document / tile_rows, all below hot_span.
-// The others: hot_span + (document block, word); vocabulary rows with at most `long_df` nnz are not blocked
-// (pseudo-block n_blocks), so they stay one piece.
+// Rare words (sw.rare_idx >= 0) go to the SWEEP stream, behind everything else: key = sw.base + cell * rpp + row with
+// cell = window * P + partition.  The others: hot_span + (document block, word); vocabulary rows with at most
+// `long_df` nnz are not blocked (pseudo-block n_blocks), so they stay one piece.
 static __global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, const uint32_t* __restrict__ rowid,
                                      const int32_t* __restrict__ df, int64_t nnz, int64_t V, int block_shift,
                                      uint32_t n_blocks, int32_t long_df, uint32_t n_hot, uint32_t tile_rows,
-                                     uint32_t hot_span, uint32_t* __restrict__ key) {
+                                     uint32_t hot_span, SweepMap sw, uint32_t* __restrict__ key) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nnz) return;
   const uint32_t c = cols[p];
@@ -258,8 +275,67 @@ static __global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, c
     key[p] = (rowid[p] / tile_rows) * n_hot + c;
     return;
   }
+  if (sw.rare_idx != nullptr && sw.rare_idx[c] >= 0) {
+    uint32_t part, row;
+    sweep_place((uint32_t)sw.rare_idx[c], sw.P, part, row);
+    key[p] = sw.base + ((rowid[p] >> sw.win_shift) * sw.P + part) * sw.rpp + row;
+    return;
+  }
   const uint32_t b = df[c] > long_df ? (rowid[p] >> block_shift) : n_blocks;
   key[p] = hot_span + (uint32_t)((uint64_t)b * (uint64_t)V + c);
+}
+
+// rare[c] = 1 for the words of the sweep stream: not in the tile stream, at most long_df nnz, at least one
+static __global__ void rare_mark_kernel(const int32_t* __restrict__ df, int64_t V, uint32_t n_hot, int32_t long_df,
+                                        int32_t* __restrict__ rare, int32_t* __restrict__ rare_df) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= V) return;
+  const int r = (c >= n_hot && df[c] > 0 && df[c] <= long_df) ? 1 : 0;
+  rare[c] = r;
+  rare_df[c] = r ? df[c] : 0;
+}
+// rare_idx: exclusive scan of rare[] -> -1 for the others; words[row * P + part] = c (pre-set to -1)
+static __global__ void rare_place_kernel(const int32_t* __restrict__ rare, int32_t* __restrict__ rare_idx, int64_t V,
+                                         uint32_t P, int32_t* __restrict__ words) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= V) return;
+  if (!rare[c]) {
+    rare_idx[c] = -1;
+    return;
+  }
+  uint32_t part, row;
+  sweep_place((uint32_t)rare_idx[c], P, part, row);
+  words[(int64_t)row * P + part] = (int32_t)c;
+}
+// cell_start[c] = first position of the (sorted) sweep keys with key >= base + c * rpp, c = 0 .. n_cells
+static __global__ void sweep_cells_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t base, uint32_t rpp,
+                                          int64_t n_cells, int32_t* __restrict__ cell_start) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_cells) return;
+  const uint64_t want = (uint64_t)base + (uint64_t)c * rpp;
+  int64_t lo = 0, hi = n;  // first index with keys[i] >= want
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((uint64_t)keys[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  cell_start[c] = (int32_t)lo;
+}
+// seg[cell * ngw + g] = start of the g-th of ngw near-equal parts of the cell, moved forward to the next word boundary
+// (a word of a window is accumulated by one lane group); seg[n_cells * ngw] = n.
+static __global__ void sweep_segs_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ cell_start,
+                                         int64_t n_cells, int ngw, int32_t* __restrict__ seg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_cells * ngw) return;
+  if (i == n_cells * ngw) {
+    seg[i] = cell_start[n_cells];
+    return;
+  }
+  const int64_t c = i / ngw;
+  const int g = (int)(i - c * ngw);
+  const int32_t cs = cell_start[c], ce = cell_start[c + 1];
+  int32_t t = cs + (int32_t)(((int64_t)(ce - cs) * g) / ngw);
+  while (t > cs && t < ce && keys[t] == keys[t - 1]) ++t;
+  seg[i] = t;
 }
 
 // flag[p] = 1 where a new piece starts (key differs from the previous nnz).
@@ -297,18 +373,27 @@ static __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const
 }
 
 // sorted position i <- original nnz perm[i]; the first n_hot_nnz positions are the TILE stream (gather index local
-// to the tile), the rest the blocked stream
+// to the tile), the last n_sweep positions the SWEEP stream (document id + accumulator row, from the key), the rest
+// the blocked stream
 template <typename T>
 __global__ void gather_transposed_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowid,
                                          const T* __restrict__ vals, int64_t nnz, int64_t n_hot_nnz, uint32_t tile_rows,
                                          uint32_t* __restrict__ h_cols, T* __restrict__ h_vals,
-                                         uint32_t* __restrict__ t_cols, T* __restrict__ t_vals) {
+                                         uint32_t* __restrict__ t_cols, T* __restrict__ t_vals,
+                                         int64_t n_sweep = 0, const uint32_t* __restrict__ keys = nullptr, uint32_t sweep_base = 0,
+                                         uint32_t rpp = 1, uint32_t* __restrict__ s_docs = nullptr,
+                                         uint32_t* __restrict__ s_rows = nullptr, T* __restrict__ s_vals = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
   const uint32_t p = perm[i];
   if (i < n_hot_nnz) {
     h_cols[i] = rowid[p] % tile_rows;
     h_vals[i] = vals[p];
+  } else if (i >= nnz - n_sweep) {
+    const int64_t o = i - (nnz - n_sweep);
+    s_docs[o] = rowid[p];
+    s_rows[o] = (keys[i] - sweep_base) % rpp;
+    s_vals[o] = vals[p];
   } else {
     t_cols[i - n_hot_nnz] = rowid[p];
     t_vals[i - n_hot_nnz] = vals[p];

@@ -482,6 +482,174 @@ __global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Synchronised sweep: X^T.B for the RARE words (the ones the blocked stream leaves uncut: their nnz gather rows of B
+// scattered over the whole table, one 256-byte row from the fabric each, at the ~29 G rows/s the fabric delivers in
+// random order -- 0.8 ms of the 1.35 ms of X^T.W at C2).  Here every workgroup (one per CU, persistent) owns a slice of
+// the rare vocabulary, with the output rows of its words as ACCUMULATORS IN LDS, and walks its nnz in document windows
+// -- all workgroups window after window, in step (one barrier per window inside the workgroup, nothing between
+// workgroups: equal work per window keeps them within a fraction of a window of each other).  The workgroups of an XCD
+// then gather from the same few MB of B at the same time and a row fetched by one CU is an L2 hit for the others:
+// tools/probes/sweep_probe.hip measures 65 G rows/s this way against 29 G rows/s in random order.  No carries, no
+// fix-up; the sum of a word is formed in document order (windows ascending, documents ascending inside a window).
+//
+// Layout (sparse_prep / engine.hip:ensure_xt): nnz sorted by (window, partition, local row, document); cell = window *
+// P + partition; each cell is cut into NGW = 16 * NG segments at word boundaries, one per lane group of the 1024-thread
+// workgroup, so within a window a word is accumulated by exactly one lane group (read-modify-write of its LDS row, in
+// order; deterministic) and the barrier orders the windows.  seg[cell * NGW + g] .. seg[cell * NGW + g + 1] delimit the
+// segment of group g (contiguous over the whole stream, one sentinel at the end).
+template <typename T>
+struct SweepArgs {
+  const int32_t* seg;        // [n_cells * NGW + 1] nnz offsets
+  int n_windows;             // cells = n_windows * gridDim.x (partition = blockIdx.x)
+  const uint32_t* docs;      // gather index (row of B)
+  const uint32_t* lrows;     // local accumulator row of the nnz's word
+  const T* vals;
+  const T* B;                // tab_rows x ld
+  int ld;
+  int lds_ld;
+  int rpp;                   // accumulator rows per partition
+  uint32_t tab_bytes;
+  const int32_t* words;      // [rpp * P] output row of accumulator row r of partition p at r * P + p, -1: none
+  T* out;
+};
+
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(1024) void spmm_sweep_kernel(const SweepArgs<T> a) {
+  constexpr int VEC = VecOf<T>::N;
+  using VT = typename VecOf<T>::type;
+  using U4 = __attribute__((ext_vector_type(4))) unsigned int;
+  constexpr int NG = kWave / LPR;
+  constexpr int NGW = 16 * NG;
+  constexpr int EPL = (LPR >= 32) ? 1 : 32 / LPR;   // chunk = max(32, LPR) nnz: a segment is usually one chunk
+  constexpr int CH = LPR * EPL;
+  constexpr int U = VPL == 2 ? 4 : 8;
+  extern __shared__ __align__(16) unsigned char mnmf_smem[];
+  T* lds = reinterpret_cast<T*>(mnmf_smem);
+  const int ld = a.ld;
+  const int nvr = ld / VEC;
+  for (int i = threadIdx.x; i < a.rpp * nvr; i += blockDim.x) {
+    const int r = i / nvr, c = (i - r * nvr) * VEC;
+    VT z;
+#pragma unroll
+    for (int x = 0; x < VEC; ++x) z.v[x] = T(0);
+    *reinterpret_cast<VT*>(lds + (size_t)r * a.lds_ld + c) = z;
+  }
+  const int lane = threadIdx.x & 63;
+  const int gi = lane / LPR, li = lane % LPR;
+  const int g = (threadIdx.x >> 6) * NG + gi;
+  bool colok[VPL];
+  uint32_t cbytes[VPL];
+#pragma unroll
+  for (int w = 0; w < VPL; ++w) {
+    const int coff = (w * LPR + li) * VEC;
+    colok[w] = coff < ld;
+    cbytes[w] = colok[w] ? (uint32_t)coff * (uint32_t)sizeof(T) : 0u;
+  }
+  const uint32_t rowbytes = (uint32_t)ld * (uint32_t)sizeof(T);
+  const uint32_t lds_rowbytes = (uint32_t)a.lds_ld * (uint32_t)sizeof(T);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.B), 0, a.tab_bytes, 0x00020000);
+  const int64_t P = gridDim.x;
+  // this group's segment of window w: seg[(w * P + blockIdx.x) * NGW + g]
+  auto seg_at = [&](int w) { return a.seg + ((int64_t)w * P + blockIdx.x) * NGW + g; };
+  // the first chunk of a segment, fetched one window ahead (its bounds two windows ahead)
+  uint32_t dn[EPL], rn[EPL];
+  T vn[EPL];
+  int s_next = 0, e_next = 0, s_next2 = 0, e_next2 = 0;
+  auto fetch_chunk = [&](int s0, int len) {
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+      const int q = li * EPL + x;
+      dn[x] = q < len ? a.docs[s0 + q] : 0u;
+      rn[x] = q < len ? a.lrows[s0 + q] : 0u;
+      vn[x] = q < len ? a.vals[s0 + q] : T(0);
+    }
+  };
+  if (a.n_windows > 0) {
+    s_next = seg_at(0)[0];
+    e_next = seg_at(0)[1];
+    fetch_chunk(s_next, e_next - s_next);
+  }
+  if (a.n_windows > 1) {
+    s_next2 = seg_at(1)[0];
+    e_next2 = seg_at(1)[1];
+  }
+  __syncthreads();   // accumulators are zero
+  for (int w = 0; w < a.n_windows; ++w) {
+    const int s0 = s_next, len = e_next - s_next;
+    uint32_t dl[EPL], rl[EPL];
+    T vl[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+      dl[x] = dn[x];
+      rl[x] = rn[x];
+      vl[x] = vn[x];
+    }
+    s_next = s_next2;
+    e_next = e_next2;
+    if (w + 1 < a.n_windows) fetch_chunk(s_next, e_next - s_next);
+    if (w + 2 < a.n_windows) {
+      s_next2 = seg_at(w + 2)[0];
+      e_next2 = seg_at(w + 2)[1];
+    }
+    for (int base = 0; __any(base < len); base += CH) {
+      if (base > 0) {   // a segment longer than one chunk (rare): fetched in place
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+          const int q = base + li * EPL + x;
+          dl[x] = q < len ? a.docs[s0 + q] : 0u;
+          rl[x] = q < len ? a.lrows[s0 + q] : 0u;
+          vl[x] = q < len ? a.vals[s0 + q] : T(0);
+        }
+      }
+      static_for<CH / U>([&](auto ib) {
+        constexpr int u0 = decltype(ib)::value * U;
+        if (__any(base + u0 < len)) {   // wave-uniform: no group of this wave has nnz left in this batch
+          uint32_t c[U], r[U];
+          T v[U];
+          VT b[U][VPL];
+          static_for<U>([&](auto iu) {
+            constexpr int u = decltype(iu)::value;
+            constexpr int t = u0 + u;
+            c[u] = (uint32_t)group_bcast_i<LPR, t / EPL>((int)dl[t % EPL], lane);
+            r[u] = (uint32_t)group_bcast_i<LPR, t / EPL>((int)rl[t % EPL], lane);
+            v[u] = group_bcast_t<LPR, t / EPL>(vl[t % EPL], lane);
+          });
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w2 = 0; w2 < VPL; ++w2) {
+              const U4 gth = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(c[u], rowbytes) + cbytes[w2], 0, 0);
+              __builtin_memcpy(&b[u][w2], &gth, sizeof(VT));
+            }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (base + u0 + u < len) {   // per lane group; the accumulator row belongs to this group in this window
+              char* row = reinterpret_cast<char*>(lds) + __umul24(r[u], lds_rowbytes);
+#pragma unroll
+              for (int w2 = 0; w2 < VPL; ++w2) {
+                if (colok[w2]) {
+                  VT acc = *reinterpret_cast<VT*>(row + cbytes[w2]);
+#pragma unroll
+                  for (int x = 0; x < VEC; ++x) acc.v[x] += v[u] * b[u][w2].v[x];
+                  *reinterpret_cast<VT*>(row + cbytes[w2]) = acc;
+                }
+              }
+            }
+          }
+        }
+      });
+    }
+    __syncthreads();   // the next window's owner of a row may be another lane group
+  }
+  // accumulators -> output rows
+  for (int i = threadIdx.x; i < a.rpp * nvr; i += blockDim.x) {
+    const int r = i / nvr, c = (i - r * nvr) * VEC;
+    const int32_t word = a.words[(int64_t)r * P + blockIdx.x];
+    if (word >= 0) *reinterpret_cast<VT*>(a.out + (int64_t)word * ld + c) = *reinterpret_cast<const VT*>(lds + (size_t)r * a.lds_ld + c);
+  }
+}
+
 template <typename T>
 __global__ void zero_rows_kernel(const int32_t* __restrict__ rows, int64_t n, int ld, T* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -245,3 +245,39 @@ def test_spmm_long_carry_lists(small_segment_engines, dtype, k):
     eng.set_matrix(Xl)
     B = rng.rand(4000, k)
     assert rel(host(eng.spmm(B)), Xl @ B) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp64", "fp32"])
+@pytest.mark.parametrize("k", [1, 7, 10, 20, 50, 64, 100, 130])
+def test_spmm_transposed_through_the_sweep_stream(dtype, k, monkeypatch):
+    """X^T.A with the rare words forced through the synchronised sweep (spmm_sweep_kernel: CU-owned vocabulary slices with
+    LDS accumulators, nnz in document windows; MNMF_SWEEP=2 takes it whatever the size, and tiny windows / a small LDS
+    budget make a test-sized matrix span many windows and rows per partition): same products as scipy, rows without nnz
+    exactly 0, bit-identical on a second call and to the default engine's sum order up to rounding."""
+    from manta_amd.engine import Engine
+
+    monkeypatch.setenv("MNMF_SWEEP", "2")
+    monkeypatch.setenv("MNMF_SWEEP_WIN_BYTES", "16384")
+    X = make_x(3000, 2500, seed=100 + k)
+    eng = Engine(dtype=dtype)
+    try:
+        eng.set_matrix(X)
+        rng = np.random.RandomState(k)
+        A = rng.rand(3000, k)
+        B = rng.rand(2500, k)
+        got = host(eng.spmm(A, transpose=True))
+        assert rel(got, X.T @ A) <= TOL[dtype]
+        assert np.all(got[np.diff(X.tocsc().indptr) == 0] == 0)
+        assert np.array_equal(got, host(eng.spmm(A, transpose=True)))
+        assert rel(host(eng.spmm(B)), X @ B) <= TOL[dtype]
+        As = 3.0 * (A - 0.5)
+        assert rel(host(eng.spmm(As, transpose=True)), X.T @ As) <= TOL[dtype] * 20
+        if k == 10:   # a short solver run on top of it
+            from oracle import nmf_oracle as oc
+            W0, H0 = rng.rand(3000, k) + 0.05, rng.rand(k, 2500) + 0.05
+            want = oc.basic_nmf(X, W0.copy(), H0.copy(), zero_threshold=1e-5, n_iter=6, check=False)
+            W, H, _ = eng.run_nmf(W0, H0, fixed_iters=6, zero_threshold=1e-5)
+            assert rel(host(W), want["W"]) <= (1e-10 if dtype == "fp64" else 1e-4)
+            assert rel(host(H), want["H"]) <= (1e-10 if dtype == "fp64" else 1e-4)
+    finally:
+        eng.close()
