@@ -98,6 +98,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only rehearses the N>1 path with several ranks on one GPU (exchange staged through the host)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="--gpus 1 only: an RCCL group of one rank with the collective hook forced on, so that the whole "
+                         "sharded schedule (reduce-scatter, slice update, all-gather) runs and its cost on one GPU shows")
     return ap.parse_args()
 
 
@@ -144,6 +147,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    elif args.rehearse_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29688")
+        os.environ["MNMF_RS_AG"] = "2"      # read at mnmf_create: slices also in a group of one
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     def all_reduce(t, op=None):
         """all-reduce of a small device tensor on whichever backend is in use"""
@@ -193,8 +201,8 @@ def main():
     eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(m_loc, V))
     torch.cuda.synchronize()
     t_prep = time.time() - t_prep
-    if world > 1:
-        eng.set_process_group()
+    if world > 1 or args.rehearse_rccl:
+        eng.set_process_group(single_rank_hook=args.rehearse_rccl)
 
     # ---- seeded uniform(0, max X) init (the reference's nmf_initialization_random), seed 42
     g = torch.Generator(device=dev)
@@ -281,7 +289,7 @@ def main():
             "config": {"workload": f"{method} MU, {m} docs x {V} vocab, density {density}, k={k} "
                                    + ("(custom size)" if custom else "(one eighth of BASELINE.json configs[4])" if args.config == "c5shard"
                                       else f"(BASELINE.json configs[{sorted(CONFIGS).index(args.config)}])"),
-                       "nnz": nnz, "method": method, "parallelism": f"doc-shard x{world}",
+                       "nnz": nnz, "method": method, "parallelism": f"doc-shard x{world}" + (" (RCCL rehearsal: group of one)" if args.rehearse_rccl else ""),
                        "convergence_check": "every iteration (as the reference)",
                        "init": "uniform(0, max X), seed 42", "matrix": "Zipf(1.1) TF-IDF, seed 1234+rank"},
             "value_without_convergence_check": round(args.steps / dt_nocheck, 3),
@@ -289,7 +297,7 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "set_matrix": round(t_prep, 2)},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

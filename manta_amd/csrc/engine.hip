@@ -67,6 +67,7 @@ struct Tune {
   int pack_exchange = 1;              // sharded runs: all-reduce only the k live columns of ld-padded rows
   int wide_gram = 1;                  // symmetric Grams with 128 < ld <= 256: tiles split over the waves of a workgroup
   int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
+  int side_prio = -1;                 // priority of the side stream: -1 low, 0 as the caller's stream, 1 high
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
                                       // stream (half of a CU's registers stay free for it), 1024 when it runs alone
@@ -108,6 +109,7 @@ struct Tune {
     wide_gram = (int)geti("MNMF_WIDE_GRAM", wide_gram);
     pack_exchange = (int)geti("MNMF_PACK_EXCHANGE", pack_exchange);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
+    side_prio = (int)geti("MNMF_SIDE_PRIO", side_prio);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
     if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
     tile_threads = std::max(256, std::min(1024, tile_threads / 64 * 64));
@@ -817,11 +819,7 @@ class Engine : public ImplBase {
       if (Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
       const bool fork = tune.xt_overlap && Xt.nnz > 0;
       if (fork) {
-        if (!side_stream) {
-          E_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-          E_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-          E_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        }
+        MNMF_TRY(ensure_side_stream());
         E_HIP(hipEventRecord(ev_fork, ctx->stream));
         E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
       }
@@ -846,11 +844,7 @@ class Engine : public ImplBase {
       // issue: enqueue them on two streams so the CUs run both at once.  They write disjoint rows of `out`,
       // except that the blocked stream first zeroes the rows it has no nnz for (the tile stream's rows among
       // them): that happens before the fork.
-      if (!side_stream) {
-        E_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-        E_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        E_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-      }
+      MNMF_TRY(ensure_side_stream());
       MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 1));   // segments + zero rows only
       MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
       // The tile kernel's workgroups need most of a CU (LDS, registers): they are launched first, on the caller's
@@ -868,6 +862,23 @@ class Engine : public ImplBase {
     }
     MNMF_TRY(spmm_stream(M, B, ld, out, lpr, vpl, ng, lds_ld));
     if (&M == &Xt && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld));
+    return 0;
+  }
+
+  // The second stream of X^T.W.  HIP hands streams to a few hardware queues in turn (4 per process on the target
+  // boxes) and two streams on one queue run one after the other: with the streams a process group creates before the
+  // engine, the side stream landed on the caller's queue and the overlap was gone (X^T.W 1.34 -> 1.86 ms at configs[1],
+  // kernel trace of the RCCL rehearsal).  Streams of another priority come from another set of queues, whatever else
+  // the process has created.
+  int ensure_side_stream() {
+    if (side_stream) return 0;
+    int lo = 0, hi = 0;   // numerically lowest = highest priority
+    E_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int prio = tune.side_prio > 0 ? lo : tune.side_prio < 0 ? hi : 0;
+    if (tune.side_prio != 0 && lo != hi) E_HIP(hipStreamCreateWithPriority(&side_stream, hipStreamNonBlocking, prio));
+    else E_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    E_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    E_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     return 0;
   }
 
@@ -1240,7 +1251,7 @@ class Engine : public ImplBase {
   // The vocabulary rows of the exchanged V x ld matrices are cut into n_ranks equal slices of slice_rows() rows (the
   // buffers are allocated with the padded row count and the padding rows stay zero: the SpMM never writes them and a
   // multiplicative update of a zero row is zero).  Rank r owns rows [r * slice_rows, (r + 1) * slice_rows).
-  bool use_slices() const { return ctx->comm != nullptr && ctx->n_ranks > 1 && tune.rs_ag; }
+  bool use_slices() const { return ctx->comm != nullptr && tune.rs_ag && (ctx->n_ranks > 1 || tune.rs_ag >= 2); }
   int64_t slice_rows() const { return use_slices() ? cdiv(V, ctx->n_ranks) : V; }
   int64_t padded_V() const { return use_slices() ? slice_rows() * ctx->n_ranks : V; }
   // live columns on the wire only when at least a quarter of a padded row is padding (as allreduce_rows)

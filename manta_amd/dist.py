@@ -30,15 +30,16 @@ def shard_csr(X, rank: int, world: int):
 
 
 def run_sharded(method: str, X_local, W0_local, H0, S0=None, *, dtype="fp64", device=None, group=None,
-                collectives=True, **opts):
+                collectives=True, single_rank_hook=False, **opts):
     """Run one solver on this rank's document shard; returns (W_local, H[, S], stats).
-    Requires an initialised torch.distributed process group (nccl on GPUs)."""
+    Requires an initialised torch.distributed process group (nccl on GPUs).  ``single_rank_hook``: install the
+    collective hook even in a group of one (rehearsal of the RCCL calls on a one-GPU box)."""
     from .engine import Engine
 
     eng = Engine(device=device, dtype=dtype)
     try:
         eng.set_matrix(X_local)
-        eng.set_process_group(group, collectives=collectives)
+        eng.set_process_group(group, collectives=collectives, single_rank_hook=single_rank_hook)
         if method == "nmf":
             return eng.run_nmf(W0_local, H0, **opts)
         if method == "pnmf":

@@ -154,14 +154,17 @@ class Engine:
                                            "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(holder, device=self.device)
 
-    def set_process_group(self, group=None, collectives=True):
+    def set_process_group(self, group=None, collectives=True, single_rank_hook=False):
         """Install the collective hook over ``torch.distributed`` (nccl = RCCL over xGMI): all-reduce,
         reduce-scatter and all-gather run IN PLACE on tensors that alias the engine's exchange buffers, no staging
         copies.  With the gloo backend (tests: several ranks on one GPU) the same operations are staged through the
-        host.  ``collectives=False`` installs the older all-reduce-only hook (all-reduce + replicated H update)."""
+        host.  ``collectives=False`` installs the older all-reduce-only hook (all-reduce + replicated H update).
+        A group of one rank needs no hook and gets none, unless ``single_rank_hook`` asks for it (together with
+        ``MNMF_RS_AG=2`` the engine then walks the whole sharded schedule on one GPU: how the RCCL calls are rehearsed
+        where no second GPU is at hand)."""
         import torch.distributed as dist
 
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not single_rank_hook):
             self._lib.mnmf_set_comm(self._h, C.cast(None, _lib.COMM_FN), None, 0, 1)
             self._lib.mnmf_set_allreduce(self._h, C.cast(None, _lib.ALLREDUCE_FN), None, 1)
             self._hook = None

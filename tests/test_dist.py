@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(args, port, nproc=2):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+def launch(args, port, nproc=2, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -77,6 +77,17 @@ def test_sharded_engine_all_reduce_hook_only(method):
 def test_sharded_engine_three_ranks_padded_slices():
     launch(["engine", "nmf", "fp32", "check"], 29645, nproc=3)
     launch(["engine", "nmtf", "fp64"], 29646, nproc=7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,dtype", [("nmf", "fp32"), ("nmtf", "fp64"), ("pnmf", "fp32")])
+def test_rccl_calls_in_a_group_of_one(method, dtype):
+    """The nccl (= RCCL) branch of the hook on the one GPU this box has: a group of one rank, hook forced on, the
+    engine forced through reduce-scatter -> slice update -> all-gather (MNMF_RS_AG=2).  The sums are trivial; what is
+    checked is that RCCL accepts the in-place calls on tensors aliasing the engine's buffers and that they are ordered
+    against the engine's kernels (the result must still be the oracle's)."""
+    launch(["nccl1", method, dtype, "check"], 29661 + ["nmf", "pnmf", "nmtf"].index(method), nproc=1, MNMF_RS_AG="2",
+           HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
 @pytest.mark.gpu
