@@ -108,6 +108,12 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
     }
     __syncthreads();
   }
+#if MNMF_ABLATE == 5 || MNMF_ABLATE == 7   // the unstaged tile must at least hold finite numbers
+  if (TILE) {
+    for (int i = threadIdx.x; i < a.tile_rows * a.lds_ld; i += blockDim.x) lds[i] = T(1);
+    __syncthreads();
+  }
+#endif
   const int lane = threadIdx.x & 63;
   const int gi = lane / LPR, li = lane % LPR;
   const int gbase = gi * LPR;
@@ -136,10 +142,12 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
     const int nrow = (int)((a.tab_rows - r0 < a.tile_rows) ? a.tab_rows - r0 : a.tile_rows);
     const int nvr = ld / VEC;
     const T* src = a.B + r0 * ld;
+#if MNMF_ABLATE != 5 && MNMF_ABLATE != 7   // 5, 7: timing experiment only, the tile is not staged
     for (int i = threadIdx.x; i < nrow * nvr; i += blockDim.x) {
       const int r = i / nvr, c = (i - r * nvr) * VEC;
       *reinterpret_cast<VT*>(lds + (size_t)r * a.lds_ld + c) = *reinterpret_cast<const VT*>(src + (size_t)r * ld + c);
     }
+#endif
     __syncthreads();
     seg_lo = a.tile_first[tile];
     seg_hi = a.tile_first[tile + 1];
@@ -244,7 +252,13 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
             const uint32_t lrow = __umul24(c[u], lds_rowbytes);  // u24: the flag bit drops out
 #pragma unroll
             for (int w = 0; w < VPL; ++w) {
+#if MNMF_ABLATE == 2 || MNMF_ABLATE == 4   // timing experiment only: no LDS read
+              const uint32_t la = lrow + lbytes[w];
+              asm volatile("" ::"v"(la));
+              const U4 l = {la, 1u, 2u, 3u};
+#else
               const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + lbytes[w]);
+#endif
               __builtin_memcpy(&b[u][w], &l, sizeof(VT));
             }
           } else if (HOT) {
@@ -280,7 +294,11 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
 #pragma unroll
           for (int w = 0; w < VPL; ++w)
 #pragma unroll
+#if MNMF_ABLATE == 3 || MNMF_ABLATE == 4   // timing experiment only: the gathered vector is waited for, not multiplied
+            for (int x = 0; x < VEC; ++x) asm volatile("" ::"v"(b[u][w].v[x]), "v"(v[u]));
+#else
             for (int x = 0; x < VEC; ++x) acc[w][x] += v[u] * b[u][w].v[x];
+#endif
           const int t = u0 + u;  // step in the chunk: held by lane t / EPL of each group, register t % EPL
           const uint64_t eb = em[t % EPL] >> (t / EPL);
           if (eb & gmask) {  // wave-uniform, scalar: some group finished a piece at this step
@@ -318,7 +336,11 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
               T* op = d >= 0 ? a.out + (int64_t)d * ld : a.carry + (int64_t)(~d) * ld;
 #pragma unroll
               for (int w = 0; w < VPL; ++w) {
+#if MNMF_ABLATE == 6 || MNMF_ABLATE == 7   // timing experiment only: finished pieces are not stored
+                if (colok[w] && d == 0x7fffffff) {
+#else
                 if (colok[w]) {
+#endif
                   VT o;
 #pragma unroll
                   for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
