@@ -72,6 +72,32 @@ def test_products_against_torch_sparse_and_adjointness(c2, dtype, tol):
         eng.close()
 
 
+def test_sweep_stream_at_full_size_equals_the_blocked_stream(c2, monkeypatch):
+    """X^T.A with MNMF_SWEEP=1 (rare words through the synchronised sweep stream where the engine's rule takes it:
+    at this size it does, tools/bench_cfgs.sh shows the sweep kernel) against the shipped default (sweep off).  The
+    sweep adds a word's nnz in document order into its accumulator row, which is the order the blocked stream uses
+    for a word it does not cut -- so the two products are the same bit for bit, not merely within tolerance."""
+    import torch
+    from manta_amd.engine import Engine
+
+    A = c2["A"].float()
+    base = Engine(dtype="fp32")
+    try:
+        base.set_matrix(rowptr=c2["rowptr"], colidx=c2["col"], vals=c2["val"], shape=(M, V))
+        want = base.spmm(A, transpose=True)
+    finally:
+        base.close()
+    monkeypatch.setenv("MNMF_SWEEP", "1")
+    eng = Engine(dtype="fp32")
+    try:
+        eng.set_matrix(rowptr=c2["rowptr"], colidx=c2["col"], vals=c2["val"], shape=(M, V))
+        got = eng.spmm(A, transpose=True)
+        assert torch.equal(got, want)
+        assert torch.equal(eng.spmm(A, transpose=True), got)
+    finally:
+        eng.close()
+
+
 def test_nmf_iterations_full_size(c2):
     import torch
     from manta_amd.engine import Engine
