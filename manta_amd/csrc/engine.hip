@@ -1458,9 +1458,11 @@ class Engine : public ImplBase {
     E_HIP(Ex.ensure(hsz + gsz));       // [Nh (V x ld) | WtW (ld x ld)]: one all-reduce
     E_HIP(small.ensure(4 * gsz));      // HHt, dW gram, dH gram
     T* Nh = Ex.template as<T>();
-    T* Gw = Nh + (size_t)Vp * ld;
-    T* Gh = small.template as<T>();
-    T* Gd = Gh + (size_t)ld * ld;      // [dW gram | dH gram] contiguous
+    // not sliced: w.T@w sits behind the k x V partial and is summed with it in one all-reduce.  Sliced: it sits in front
+    // of the dW Gram, which the same w update produces -- [w.T@w | dW gram] is one small all-reduce per iteration.
+    T* Gw = sliced ? small.template as<T>() : Nh + (size_t)Vp * ld;
+    T* Gh = small.template as<T>() + (sliced ? 3 : 0) * (size_t)ld * ld;
+    T* Gd = small.template as<T>() + (size_t)ld * ld;      // [dW gram | dH gram] contiguous
     if (Vp > V) {  // the padding rows of the sliced buffers are zero and stay zero
       const size_t off = (size_t)V * ld * sizeof(T), len = (size_t)(Vp - V) * ld * sizeof(T);
       E_HIP(hipMemsetAsync(Hb[0].template as<char>() + off, 0, len, st()));
@@ -1499,14 +1501,16 @@ class Engine : public ImplBase {
       T* Hc = Hb[ch].template as<T>();
       T* Hn = Hb[1 - ch].template as<T>();
       const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
-      if (!gw_valid) MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gw));  // wT_w       nmf_basic.py:39
+      if (!gw_valid) {
+        MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gw));  // wT_w       nmf_basic.py:39
+        if (sliced) MNMF_TRY(allreduce(Gw, (int64_t)ld * ld));
+      }
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
       pt.mark(1);
       if (sliced) {
         // every rank sums and updates one slice of the vocabulary, then the slices are gathered: the same bytes on
         // the wire as an all-reduce, the h update done once instead of n_ranks times, h identical on every rank
-        MNMF_TRY(allreduce(Gw, (int64_t)ld * ld));
         MNMF_TRY(reduce_scatter_rows(Nh, k, ld));
         const size_t o = (size_t)s_lo * ld;
         MNMF_TRY(rk(RK_MU, Hc + o, Gw, nullptr, nullptr, Hc + o, Nh + o, Hn + o, s_rows, ld, eps));    // :41-42
@@ -1537,8 +1541,11 @@ class Engine : public ImplBase {
       MNMF_TRY(rk_grams(RK_MU, Wc, Gh, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw, do_check ? Gd : nullptr));
       gw_valid = true;
       pt.mark(5);
+      // sliced: the next iteration's w.T@w and this iteration's dW Gram in one collective (the dH Gram is computed by
+      // every rank from the gathered h); otherwise w.T@w travels with the next k x V partial
+      if (sliced) MNMF_TRY(allreduce(Gw, (int64_t)ld * ld * (do_check ? 2 : 1)));
       if (do_check) {
-        MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
+        if (!sliced) MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
         MNMF_TRY(fetch_begin(2 * (size_t)ld * ld));
         MNMF_TRY(fetch_add(Gd, 2 * (size_t)ld * ld));
         MNMF_TRY(fetch_commit());
@@ -1937,7 +1944,8 @@ class Engine : public ImplBase {
     E_HIP(Aux1.ensure(hsz));         // M1 = hT sT, later M2 = Pt s1
     E_HIP(small.ensure(16 * gsz));
     T* Pt = Ex.template as<T>();
-    T* Gw1 = Pt + (size_t)Vp * ld;
+    // sliced: w1.T@w1 in front of the dW Gram (same w update, one all-reduce for both); otherwise behind the partial
+    T* Gw1 = sliced ? small.template as<T>() + 10 * gel : Pt + (size_t)Vp * ld;
     if (Vp > V) {  // the padding rows of the sliced buffers are zero and stay zero
       const size_t off = (size_t)V * ld * sizeof(T), len = (size_t)(Vp - V) * ld * sizeof(T);
       E_HIP(hipMemsetAsync(Hb[0].template as<char>() + off, 0, len, st()));
@@ -1955,8 +1963,8 @@ class Engine : public ImplBase {
     T* T2 = sm + 7 * gel;
     T* den_s = sm + 8 * gel;
     T* T3 = sm + 9 * gel;
-    T* Qm = sm + 10 * gel;
-    T* Gd = sm + 11 * gel;  // [dW gram | dH gram]
+    T* Qm = sm + 13 * gel;
+    T* Gd = sm + 11 * gel;  // [dW gram | dH gram]; sm + 10 * gel: w1.T@w1 of a sliced run
     // S in: k x k -> ld x ld padded
     pad_sq(S, k, ld, Sb[0]);
     E_LAUNCH();
@@ -2026,6 +2034,7 @@ class Engine : public ImplBase {
       const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
       // w update with w1.T @ w1 (:157) and, for the norms, D^T D of D = |w1 - w| (:179) in the same pass
       MNMF_TRY(rk_grams(RK_MU, Wc, Dm, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw1, do_check ? Gd : nullptr));
+      if (sliced) MNMF_TRY(allreduce(Gw1, (int64_t)gel * (do_check ? 2 : 1)));   // [w1.T@w1 | dW gram]
       pt.mark(5);
       // ---- S update                                                   nmtf.py:156-158
       pt.mark(0);
@@ -2033,7 +2042,6 @@ class Engine : public ImplBase {
       pt.mark(1);
       const size_t so = (size_t)s_lo * ld;   // this rank's slice of the vocabulary rows (everything when not sliced)
       if (sliced) {
-        MNMF_TRY(allreduce(Gw1, (int64_t)gel));
         MNMF_TRY(reduce_scatter_rows(Pt, k, ld));
         MNMF_TRY(gram(Pt + so, nullptr, Hc + so, nullptr, s_rows, ld, false, num_s));   // this slice's share of (w1.T X) @ h.T
         MNMF_TRY(allreduce(num_s, (int64_t)gel));
@@ -2062,7 +2070,7 @@ class Engine : public ImplBase {
       hht_valid = true;
       pt.mark(2);
       if (do_check) {                                                     // Frobenius norms   nmtf.py:179-181
-        MNMF_TRY(allreduce(Gd, (int64_t)gel));
+        if (!sliced) MNMF_TRY(allreduce(Gd, (int64_t)gel));
         MNMF_TRY(fetch_begin(4 * gel));
         MNMF_TRY(fetch_add(Gd, 2 * gel));          // [dW gram | dH gram]
         MNMF_TRY(fetch_add(Sb[0], 2 * gel));       // both S buffers: ||s1 - s||_F on the host
