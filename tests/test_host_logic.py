@@ -351,3 +351,4 @@ def test_cached_engine_key_is_the_gpu_not_the_spelling():
     assert nmf._device_index(0) == nmf._device_index("cuda:0") == nmf._device_index(torch.device("cuda", 0)) == 0
     assert nmf._device_index(torch.device("cuda", 3)) == 3
     assert isinstance(nmf._device_index(None), int)
+
