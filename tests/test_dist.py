@@ -107,3 +107,21 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "doc-shard x2"
+
+
+@pytest.mark.gpu
+def test_bench_rehearses_the_rccl_schedule_on_one_gpu():
+    """`python bench.py --rehearse-rccl`: an nccl group of one rank, the collective hook forced on, the whole sharded
+    schedule through RCCL -- one JSON line, marked as a rehearsal, n_gpus 1."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="2", MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--config", "c1",
+           "--rehearse-rccl", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "RCCL rehearsal" in d["config"]["parallelism"]
