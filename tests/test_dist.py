@@ -80,6 +80,15 @@ def test_sharded_engine_three_ranks_padded_slices():
 
 
 @pytest.mark.gpu
+def test_sharded_engine_four_ranks():
+    """the result must not depend on the number of ranks beyond summation order -- 2, 3 and 7 ranks above,
+    4 here; every case is checked against the unsharded oracle within the dtype's tolerance and H must be bit-identical
+    on all ranks.  (The 8-rank run is the driver's.)"""
+    launch(["engine", "nmf", "fp32", "check"], 29647, nproc=4)
+    launch(["engine", "pnmf", "fp64", "check"], 29648, nproc=4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method,dtype", [("nmf", "fp32"), ("nmtf", "fp64"), ("pnmf", "fp32")])
 def test_rccl_calls_in_a_group_of_one(method, dtype):
     """The nccl (= RCCL) branch of the hook on the one GPU this box has: a group of one rank, hook forced on, the
