@@ -76,7 +76,8 @@ struct Tune {
   int mfma_gram = 1;                  // fp32 Gram products on the matrix cores
   int fuse_grams = 1;                 // Grams of the new factor / of |new - old| inside the update kernel (k <= 64)
   int mfma_rk = 1;                    // fp32 rows x (k x k) products + update on the matrix cores
-  int64_t hot_min_nnz = 1 << 20;      // use the LDS-staged persistent SpMM only for matrices at least this big
+  int64_t hot_min_nnz = 1 << 20;      // X^T.W tile stream (and, when set through the environment, X.H^T too): smallest matrix
+  int64_t hot_x_min_nnz = -1;         // X.H^T: smallest matrix that takes the LDS-hot kernel; -1 = the measured rule (hot_x_threshold)
   int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
   int sweep = 0;                      // X^T.W: rare words through the synchronised sweep (0 off: measured 1.6 % slower at C2; 1 when the shape suits it; 2 always: tests)
@@ -98,6 +99,7 @@ struct Tune {
     ld_align = (int)geti("MNMF_LD_ALIGN", ld_align);
     permute_vocab = (int)geti("MNMF_PERMUTE_VOCAB", permute_vocab);
     hot_lds_bytes = geti("MNMF_HOT_LDS_BYTES", hot_lds_bytes);
+    hot_x_min_nnz = geti("MNMF_HOT_X_MIN_NNZ", std::getenv("MNMF_HOT_MIN_NNZ") ? geti("MNMF_HOT_MIN_NNZ", hot_min_nnz) : hot_x_min_nnz);
     hot_min_nnz = geti("MNMF_HOT_MIN_NNZ", hot_min_nnz);
     xt_hot_words = (int)geti("MNMF_XT_HOT_WORDS", xt_hot_words);
     tile_lds_bytes = geti("MNMF_TILE_LDS_BYTES", tile_lds_bytes);
@@ -882,6 +884,23 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  // Smallest X (nnz) for which X.H^T takes the LDS-hot kernel rather than the plain stream kernel, by lanes per factor
+  // row.  The hot kernel pays a fixed price (one 1024-thread workgroup per CU stages the table; 16 waves per CU; a select
+  // between the LDS and the memory operand on every step) for serving the frequent half of the nnz from LDS.  Measured
+  // on MI355X (tools/sweep_hotmin.sh, Zipf matrices, X.H^T ms hot / plain): 16 lanes (256-byte rows) 7.9e6 nnz
+  // 0.167 / 0.143, 1.2e7 0.204 / 0.215, 9.8e7 1.17 / 1.39; 8 lanes (128-byte rows) 2.5e7 0.297 / 0.273, 4.9e7
+  // 0.444 / 0.474; 64 lanes 1.2e7 0.595 / 0.580, 4.9e7 2.14 / 2.22; 32 lanes (two nnz per step: the select costs what
+  // the LDS saves) 9.8e7 fp32 k = 70 2.43 / 1.98, k = 100 2.50 / 2.47, fp64 k = 50 2.91 / 2.62, 4.9e8 18.1 / 17.4.
+  int64_t hot_x_threshold(int lpr) const {
+    if (tune.hot_x_min_nnz >= 0) return tune.hot_x_min_nnz;
+    switch (lpr) {
+      case 16: return 10000000;
+      case 32: return INT64_MAX;
+      case 64: return 30000000;
+      default: return 35000000;
+    }
+  }
+
   // part: 0 = everything, 1 = preparation (segments, carry buffer, zeroing of empty rows), 2 = kernels only
   int spmm_stream(StreamMat<T>& M, const T* B, int ld, T* out, int lpr, int vpl, int ng, int lds_ld, int part = 0) {
     int64_t q = (&M == &Xt) ? tune.xt_q : (&M == &Xth) ? tune.xth_q : tune.x_q;
@@ -891,7 +910,7 @@ class Engine : public ImplBase {
       while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
       // the persistent LDS-hot kernel hands segments to n_cus x 16 waves: keep about six rounds of them, or the last
       // round's idle tail shows (measured on 1/8 and 1/4 shards of C2: X.H^T -13 % / -5 %)
-      if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= tune.hot_min_nnz)
+      if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= hot_x_threshold(lpr))
         while (q > 32 && M.nnz / q < (int64_t)11 * n_cus * 16 * ng / 2) q >>= 1;
     }
     const int xcd_group = (&M == &Xt && tune.xcd_affinity && Xt.pieces.block.size() == Xt.pieces.row.size() &&
@@ -908,7 +927,7 @@ class Engine : public ImplBase {
     }
     // X direction: stage the most frequent rows of the (renumbered) factor in LDS
     int hot = 0;
-    if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= tune.hot_min_nnz &&
+    if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= hot_x_threshold(lpr) &&
         (int64_t)M.tab_rows * ld * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
       hot = (int)std::min<int64_t>(M.tab_rows, tune.hot_lds_bytes / ((int64_t)lds_ld * (int64_t)sizeof(T)));
       if (hot < 16) hot = 0;

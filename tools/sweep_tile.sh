@@ -1,0 +1,10 @@
+# X^T.W with the LDS tile stream (default) against the blocked stream alone (MNMF_XT_HOT_WORDS=0)
+cd $GRAFT_REPO_ROOT
+one() { echo "== $*"; env $1 timeout -k 10 200 python -u bench.py ${@:2} --steps ${STEPS:-20} --warmup 5 --no-cpu 2>/dev/null | grep '^{' | python3 -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); p=d['roofline']['phase_ms_per_iter']; print(d['config']['nnz'], d['value'], p['spmm_xt'], p['spmm_x'])" || exit 1; }
+for args in "$@"; do
+  one MNMF_XT_HOT_WORDS=512 $args
+  one MNMF_XT_HOT_WORDS=0 $args
+done
