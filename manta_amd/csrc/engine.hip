@@ -53,7 +53,7 @@ struct DevBuf {
 struct Tune {
   int64_t x_q = 512;                  // target nnz per segment, X stream
   int64_t xt_q = 128;                 // target nnz per segment, X^T stream (small: one XCD stays inside one document block)
-  int64_t xt_block_bytes = 4 << 20;   // bytes of W rows per document block of X^T (upper limit; see spmm())
+  int64_t xt_block_bytes = 0;         // bytes of W rows per document block of X^T (upper limit; see spmm()); 0 = 4 MiB, 8 MiB at 32 lanes per row
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
@@ -771,7 +771,7 @@ class Engine : public ImplBase {
       MNMF_TRY(ensure_prepared());
       if (&M == &Xt) {
         int bs = 8;
-        while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= tune.xt_block_bytes) ++bs;
+        while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= xt_block_limit(64)) ++bs;
         MNMF_TRY(ensure_xt(bs, 0, 0));
       }
       MNMF_TRY(spmm_stream(M, B, ld, out, 64, 2, 1, ld, 1));   // segments, carry buffer, empty rows
@@ -794,7 +794,7 @@ class Engine : public ImplBase {
       // 2 MiB +0.6 / +2.7 / +1.9 %, 8 MiB -4 %: fewer pieces and carries against L2 residency), but never so large that
       // a small matrix is left with fewer than about four blocks (C1, 2.5 MB of W: one block -13 %, four or more +9 %)
       const int64_t w_bytes = std::max<int64_t>(m, 1) * ld * (int64_t)sizeof(T);
-      const int64_t block_bytes = std::min<int64_t>(tune.xt_block_bytes, std::max<int64_t>((int64_t)256 << 10, w_bytes / 4));
+      const int64_t block_bytes = std::min<int64_t>(xt_block_limit(lpr), std::max<int64_t>((int64_t)256 << 10, w_bytes / 4));
       int bs = 8;
       while (bs < 20 && ((int64_t)2 << bs) * ld * (int64_t)sizeof(T) <= block_bytes) ++bs;
       // tile stream for the most frequent words: documents per tile = what one workgroup's LDS holds
@@ -882,6 +882,14 @@ class Engine : public ImplBase {
     E_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     E_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     return 0;
+  }
+
+  // Document block of the X^T blocked stream: 4 MiB of W rows (one XCD's L2) measured best at 128-, 256-, 832- and
+  // 896-byte rows; rows of 448-512 bytes (32 lanes per row: configs[2], fp64 configs[1]) gain 2-5 % on X^T.W with
+  // 8 MiB (tools/sweep_block.sh: 2.80 -> 2.66 ms, 3.23 -> 3.11 ms), the others lose 3 % or more there.
+  int64_t xt_block_limit(int lpr) const {
+    if (tune.xt_block_bytes > 0) return tune.xt_block_bytes;
+    return lpr == 32 ? (int64_t)8 << 20 : (int64_t)4 << 20;
   }
 
   // Smallest X (nnz) for which X.H^T takes the LDS-hot kernel rather than the plain stream kernel, by lanes per factor
@@ -1092,6 +1100,7 @@ class Engine : public ImplBase {
       if (tune.mfma_rk && ld <= 256 && (ld <= 32 || ld % 16 == 0)) return rk_mfma(mode, a);
     } else {
       if (can_fuse(ld)) return rk64(mode, a, nullptr, nullptr);
+      if (tune.mfma_rk && tune.mfma_f64 && ld > 64 && ld <= 128 && ld % 16 == 0) return rk64_wide(mode, a);
     }
     dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(ld, 64));
     if (mode == RK_PROD) dense_rk_kernel<T, RK_PROD><<<grid, 256, 0, st()>>>(a);
@@ -1193,6 +1202,26 @@ class Engine : public ImplBase {
     if (mode == RK_PROD) return rk64_launch<NT, RK_PROD>(a, nullptr, nullptr);
     if (mode == RK_MU) return rk64_launch<NT, RK_MU>(a, gram_new, gram_diff);
     return rk64_launch<NT, RK_MU_SQRT>(a, gram_new, gram_diff);
+  }
+  // 64 < ld <= 128 (k = 65 ... 128 in fp64): product / update on the matrix cores without the fused Grams (their
+  // accumulators would not fit the register file next to 5 ... 8 column tiles); the Grams stay separate passes
+  template <int NT>
+  int rk64_wide_nt(int mode, const RkArgs<double>& a) {
+    const int64_t n_tiles = cdiv(a.rows, 16);
+    const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n_tiles, 4), 2 * (int64_t)n_cus));
+    if (mode == RK_PROD) dense_rk_mfma_f64_kernel<NT, RK_PROD, 0><<<nb, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    else if (mode == RK_MU) dense_rk_mfma_f64_kernel<NT, RK_MU, 0><<<nb, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    else dense_rk_mfma_f64_kernel<NT, RK_MU_SQRT, 0><<<nb, 256, 0, st()>>>(a, n_tiles, nullptr, nullptr);
+    E_LAUNCH();
+    return 0;
+  }
+  int rk64_wide(int mode, const RkArgs<double>& a) {
+    switch (a.ld / 16) {
+      case 5: return rk64_wide_nt<5>(mode, a);
+      case 6: return rk64_wide_nt<6>(mode, a);
+      case 7: return rk64_wide_nt<7>(mode, a);
+      default: return rk64_wide_nt<8>(mode, a);
+    }
   }
   int rk64(int mode, const RkArgs<double>& a, double* gram_new, double* gram_diff) {
     switch (a.ld / 16) {
