@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmnmf.so")
 OBJ = os.path.join(CSRC, "_obj")
 _ENGINE_DEPS = ["ctx.hpp", "impl_base.hpp", "common.hpp", "dense.hpp", "spmm.hpp", "sparse_prep.hpp", "eig.hpp", "gram_mfma.hpp",
-                "rk_mfma_f64.hpp", "topk.hpp", "histogram.hpp"]
+                "rk_mfma_f64.hpp", "gram_mfma_f64.hpp", "topk.hpp", "histogram.hpp"]
 # object -> (source, extra flags, the files it includes).  Engine<float> and Engine<double> are separate objects so
 # the four compiles run side by side.
 UNITS = {

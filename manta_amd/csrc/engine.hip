@@ -17,6 +17,7 @@
 #include "gram_mfma.hpp"
 #include "histogram.hpp"
 #include "rk_mfma_f64.hpp"
+#include "gram_mfma_f64.hpp"
 #include "sparse_prep.hpp"
 #include "spmm.hpp"
 #include "topk.hpp"
@@ -1026,6 +1027,22 @@ class Engine : public ImplBase {
     return 0;
   }
 
+  template <int NT>
+  int gram64_launch(const double* A, const double* A2, int64_t rows, bool diff, double* out) {
+    const int64_t elems = (int64_t)(16 * NT) * (16 * NT);
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(2 * n_cus, cdiv(rows, 256)));
+    const int64_t rpb = round_up(cdiv(rows, blocks), 16);
+    const int64_t nb = cdiv(rows, rpb);
+    E_HIP(slab.ensure((size_t)nb * elems * sizeof(double)));
+    double* sl = slab.template as<double>();
+    if (diff) gram_mfma_f64_kernel<NT, true><<<(unsigned)nb, 256, 0, st()>>>(A, A2, rows, rpb, sl);
+    else gram_mfma_f64_kernel<NT, false><<<(unsigned)nb, 256, 0, st()>>>(A, A2, rows, rpb, sl);
+    E_LAUNCH();
+    slab_reduce_kernel<double><<<(unsigned)cdiv(elems, 16), 256, 0, st()>>>(sl, nb, elems, out);
+    E_LAUNCH();
+    return 0;
+  }
+
   // symmetric Gram of a wide factor (5..8 column tiles): the waves of a workgroup split the tiles (gram_mfma.hpp)
   template <int NT>
   int gram_mfma_wide_launch(const float* A, const float* A2, int64_t rows, int ld, bool diff, float* out) {
@@ -1074,6 +1091,20 @@ class Engine : public ImplBase {
           case 6: return gram_mfma_launch<6, 1>(a, a2, b, b2, rows, ld, diff, o);
           case 7: return gram_mfma_launch<7, 1>(a, a2, b, b2, rows, ld, diff, o);
           default: return gram_mfma_launch<8, 1>(a, a2, b, b2, rows, ld, diff, o);
+        }
+      }
+    }
+    if constexpr (sizeof(T) == 8) {
+      if (tune.mfma_gram && tune.mfma_f64 && A == B && A2 == B2 && ld % 16 == 0 && ld <= 112) {  // gram_mfma_f64.hpp (8 tiles spill)
+        const double* a = (const double*)A; const double* a2 = (const double*)A2;
+        switch (ld / 16) {
+          case 1: return gram64_launch<1>(a, a2, rows, diff, (double*)out);
+          case 2: return gram64_launch<2>(a, a2, rows, diff, (double*)out);
+          case 3: return gram64_launch<3>(a, a2, rows, diff, (double*)out);
+          case 4: return gram64_launch<4>(a, a2, rows, diff, (double*)out);
+          case 5: return gram64_launch<5>(a, a2, rows, diff, (double*)out);
+          case 6: return gram64_launch<6>(a, a2, rows, diff, (double*)out);
+          default: return gram64_launch<7>(a, a2, rows, diff, (double*)out);
         }
       }
     }
