@@ -1128,7 +1128,7 @@ class Engine : public ImplBase {
     if (rows <= 0) return 0;
     RkArgs<T> a{A1, G1, A2, G2, upd, num, out, rows, ld, (T)eps};
     if constexpr (sizeof(T) == 4) {
-      if (tune.mfma_rk && ld <= 256 && (ld <= 32 || ld % 16 == 0)) return rk_mfma(mode, a);
+      if (tune.mfma_rk && ld <= 1024 && (ld <= 32 || ld % 16 == 0)) return rk_mfma(mode, a);   // beyond 128 columns: groups of 128 (grid.y)
     } else {
       if (can_fuse(ld)) return rk64(mode, a, nullptr, nullptr);
       if (tune.mfma_rk && tune.mfma_f64 && ld > 64 && ld <= 128 && ld % 16 == 0) return rk64_wide(mode, a);

@@ -120,7 +120,8 @@ def test_gram(engines, dtype, rows, k):
 
 
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
-@pytest.mark.parametrize("rows,k", [(1, 2), (999, 7), (4096, 50), (2000, 100), (500, 200), (20000, 160), (9999, 256)])
+@pytest.mark.parametrize("rows,k", [(1, 2), (999, 7), (4096, 50), (2000, 100), (500, 200), (20000, 160), (9999, 256),
+                                    (3000, 260), (1500, 530), (700, 1000)])
 def test_update(engines, dtype, rows, k):
     eng = engines[dtype]
     rng = np.random.RandomState(rows * 7 + k)
