@@ -68,6 +68,7 @@ struct Tune {
   int pack_exchange = 1;              // sharded runs: all-reduce only the k live columns of ld-padded rows
   int wide_gram = 1;                  // symmetric Grams with 128 < ld <= 256: tiles split over the waves of a workgroup
   int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
+  int kxk_chain = 1;                  // NMTF: the k x k products of an iteration in two launches instead of nine (ld <= 32)
   int side_prio = -1;                 // priority of the side stream: -1 low, 0 as the caller's stream, 1 high
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
@@ -113,6 +114,7 @@ struct Tune {
     pack_exchange = (int)geti("MNMF_PACK_EXCHANGE", pack_exchange);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     side_prio = (int)geti("MNMF_SIDE_PRIO", side_prio);
+    kxk_chain = (int)geti("MNMF_KXK_CHAIN", kxk_chain);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
     if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
     tile_threads = std::max(256, std::min(1024, tile_threads / 64 * 64));
@@ -2059,6 +2061,10 @@ class Engine : public ImplBase {
     pt.mark(-1);
     std::vector<double> g;
     const unsigned kb = (unsigned)cdiv((int64_t)gel, 256);
+    // k x k chains in one launch each (dense.hpp) while one workgroup is quick enough: measured +14 % / +4 % / +1 %
+    // on the iteration at k = 10 / 20 (1.8e6, 1e7, 2e8 nnz), -6 % at ld = 64 (4096 elements of 64 terms on one CU)
+    const bool chain = tune.kxk_chain && ld <= 32;
+    const size_t chain_lds = 2 * gsz;
     bool hht_valid = false;  // hhT holds h @ h.T of the current h (left there by the previous h update)
     // The norms of iteration i are read while iteration i+1 is already queued up to its W update: that work only
     // writes scratch and the other halves of the ping-pong buffers, so when iteration i turns out to have converged
@@ -2088,16 +2094,24 @@ class Engine : public ImplBase {
       T* Sc = Sb[cs];
       T* Sn = Sb[1 - cs];
       // ---- W update                                                   nmtf.py:151-153
-      kxk_transpose_kernel<T><<<kb, 256, 0, st()>>>(Sc, ST, ld);
-      E_LAUNCH();
+      if (chain) {  // one launch: s^T, s (h hT), s (h hT) sT
+        if (!hht_valid) MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));  // h @ h.T
+        nmtf_chain_w_kernel<T><<<1, 1024, chain_lds, st()>>>(Sc, hhT, ST, T1, Dm, ld);
+        E_LAUNCH();
+      } else {
+        kxk_transpose_kernel<T><<<kb, 256, 0, st()>>>(Sc, ST, ld);
+        E_LAUNCH();
+      }
       MNMF_TRY(rk(RK_PROD, Hc, ST, nullptr, nullptr, nullptr, nullptr, M1, V, ld, 0));  // h.T @ s.T
       pt.mark(2);
       MNMF_TRY(spmm(X, M1, ld, Nw.template as<T>()));                             // in_mat @ (h.T @ s.T)
       pt.mark(4);
-      if (!hht_valid) MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));  // h @ h.T
-      pt.mark(3);
-      MNMF_TRY(kxk(Sc, hhT, T1, ld, 0, 0));                              // s (h hT)
-      MNMF_TRY(kxk(T1, Sc, Dm, ld, 0, 1));                               // s (h hT) sT
+      if (!chain) {
+        if (!hht_valid) MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));  // h @ h.T
+        pt.mark(3);
+        MNMF_TRY(kxk(Sc, hhT, T1, ld, 0, 0));                              // s (h hT)
+        MNMF_TRY(kxk(T1, Sc, Dm, ld, 0, 1));                               // s (h hT) sT
+      }
       if (pending) {  // norms of the previous iteration                 :179-181, :200
         const int r = resolve();
         pt.mark(6);
@@ -2128,15 +2142,22 @@ class Engine : public ImplBase {
         MNMF_TRY(allreduce_rows(Pt, (int64_t)V * ld + (int64_t)gel, k, ld));
         MNMF_TRY(gram(Pt, nullptr, Hc, nullptr, V, ld, false, num_s));  // (w1.T X) @ h.T
       }
-      MNMF_TRY(kxk(Gw1, Sc, T2, ld, 0, 0));
-      MNMF_TRY(kxk(T2, hhT, den_s, ld, 0, 0));                           // (w1T w1) s (h hT)
-      kxk_mu_kernel<T><<<kb, 256, 0, st()>>>(Sc, num_s, den_s, (T)eps, Sn, ld);
-      E_LAUNCH();
+      if (chain) {  // one launch: (w1T w1) s (h hT), the s update, s1T (w1T w1) s1
+        nmtf_chain_s_kernel<T><<<1, 1024, chain_lds, st()>>>(Gw1, Sc, hhT, num_s, (T)eps, T2, den_s, Sn, T3, Qm, ld);
+        E_LAUNCH();
+      } else {
+        MNMF_TRY(kxk(Gw1, Sc, T2, ld, 0, 0));
+        MNMF_TRY(kxk(T2, hhT, den_s, ld, 0, 0));                           // (w1T w1) s (h hT)
+        kxk_mu_kernel<T><<<kb, 256, 0, st()>>>(Sc, num_s, den_s, (T)eps, Sn, ld);
+        E_LAUNCH();
+      }
       pt.mark(3);
       // ---- H update                                                   nmtf.py:161-163
       MNMF_TRY(rk(RK_PROD, Pt + so, Sn, nullptr, nullptr, nullptr, nullptr, M1 + so, s_rows, ld, 0));  // (s1.T @ P)^T = Pt s1
-      MNMF_TRY(kxk(Sn, Gw1, T3, ld, 1, 0));                              // s1T (w1T w1)
-      MNMF_TRY(kxk(T3, Sn, Qm, ld, 0, 0));                               // s1T (w1T w1) s1   (symmetric)
+      if (!chain) {
+        MNMF_TRY(kxk(Sn, Gw1, T3, ld, 1, 0));                              // s1T (w1T w1)
+        MNMF_TRY(kxk(T3, Sn, Qm, ld, 0, 0));                               // s1T (w1T w1) s1   (symmetric)
+      }
       if (sliced) {
         MNMF_TRY(rk(RK_MU, Hc + so, Qm, nullptr, nullptr, Hc + so, M1 + so, Hn + so, s_rows, ld, eps));
         MNMF_TRY(all_gather_rows(Hn, k, ld));
