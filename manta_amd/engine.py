@@ -76,6 +76,7 @@ class Engine:
         self._hook = None      # keep the ctypes callback alive
         self._stage = None
         self._resident_key = None   # identity of the scipy matrix run_nmf last uploaded (manta_amd.nmf)
+        self._svd_cache = None      # leading right singular vectors of the resident matrix (manta_amd.init_device)
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -113,6 +114,7 @@ class Engine:
         """``X``: a scipy sparse matrix (host), or give device/host tensors ``rowptr`` (int64), ``colidx``
         (int32), ``vals`` and ``shape``.  The engine copies and keeps X and X^T resident."""
         self._resident_key = None   # whoever replaces the matrix invalidates run_nmf's residency marker
+        self._svd_cache = None      # ... and what was computed from the old matrix
         if X is not None:
             X = X.tocsr()
             X.sort_indices()

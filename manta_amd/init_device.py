@@ -46,7 +46,9 @@ def _orthonormal_columns(Z, drop: bool = True):
     for _ in range(2):
         L, bad = torch.linalg.cholesky_ex(_tsgemm(W, W))
         d = L.diagonal()
-        if int(bad) != 0 or not bool(torch.isfinite(d).all()) or float(d.min()) < 1e-5 * float(d.max()):
+        # one trip to the host for the three checks (each .item() is a stream synchronisation)
+        nbad, dmin, dmax = torch.stack([bad.double(), d.min(), d.max()]).tolist()
+        if nbad != 0 or not (math.isfinite(dmin) and math.isfinite(dmax)) or dmin < 1e-5 * dmax:
             ok = False
             break
         W = W @ torch.linalg.inv(L).t()
@@ -74,6 +76,17 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
     if k < 1 or k > min(m, V):
         raise ValueError("k out of range")
     dev, dt = eng.device, eng.tdtype
+    # The same matrix is factorised again with the same topic count when methods are compared or a run is repeated
+    # with other thresholds: the engine keeps the right singular vectors per (k, tolerance, seed, block) of its resident
+    # matrix (Engine.set_matrix drops them) and a repeated request costs one SpMM.  Only exact repeats are served --
+    # slicing or warm-starting from another k's vectors would make a result depend on the calls that came before it.
+    ckey = (k, float(tol), int(seed), int(block), max_dim)
+    cache = getattr(eng, "_svd_cache", None)
+    hit = cache.get(ckey) if isinstance(cache, dict) else None
+    if hit is not None and hit["v"].shape[0] == V and hit["v"].device == dev:
+        if info is not None:
+            info.update(steps=0, restarts=0, converged=True, dim=k, max_residual=hit["residual"], cached=True)
+        return _triplets_from_v(eng, hit["v"], k)
     b = max(1, min(block, V))
     if max_dim is None:
         max_dim = max(3 * k + 4 * b, 128)
@@ -106,7 +119,10 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
         Tn[:, old:] = C
         Tn[old:, :old] = C[:old].t()
         T = Tn
-        evals, evecs = torch.linalg.eigh(0.5 * (T + T.t()))
+        # Rayleigh-Ritz on the host: the projected matrix has a few hundred rows at most, LAPACK takes 0.3-0.7 ms
+        # including both copies where the device solver takes 1.6 ms (measured at dim = 100) -- half of a step
+        ev_h, evec_h = torch.linalg.eigh((0.5 * (T + T.t())).cpu())
+        evals, evecs = ev_h.to(dev), evec_h.to(dev)
         kk = min(k, dim)
         theta = evals[-kk:].flip(0)
         S = evecs[:, -kk:].flip(1).contiguous()
@@ -145,6 +161,18 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
     v = Q @ S                                                     # polish orthonormality (columns keep their order)
     vq = _orthonormal_columns(v, drop=False)
     v = vq if vq is not None else torch.linalg.qr(v)[0]
+    if converged:
+        if not isinstance(getattr(eng, "_svd_cache", None), dict):
+            eng._svd_cache = {}
+        if len(eng._svd_cache) >= 8:                              # a handful of V x k matrices at most
+            eng._svd_cache.pop(next(iter(eng._svd_cache)))
+        eng._svd_cache[ckey] = dict(v=v, residual=float(rn.max() / theta[0]))
+    return _triplets_from_v(eng, v, k)
+
+
+def _triplets_from_v(eng, v, k):
+    """(u, s, v) from orthonormal right singular vectors: u = X.v normalised, s = ||X.v||, sorted by s descending."""
+    m, dev, dt = eng.m, eng.device, eng.tdtype
     u = torch.empty((m, k), device=dev, dtype=torch.float64)
     for c0 in range(0, k, 128):                                   # the engine takes up to 256 (f64) columns per call
         c1 = min(k, c0 + 128)

@@ -239,12 +239,28 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
     return results
 
 
-def install(tfidf: bool = False) -> list:
+def install(tfidf: bool = False, init=None) -> list:
     """Rebind ``run_nmf`` inside an installed MANTA.  Callers bind the name at import time
     (modeling_pipeline.py:10, optimization_pipeline.py:16), so the attribute is replaced on each
     importing module.  ``tfidf=True`` also rebinds ``tf_idf_english`` / ``tf_idf_turkish`` where they are bound
-    (english_entry.py:10, turkish_entry.py:4).  Returns the module names that were patched."""
+    (english_entry.py:10, turkish_entry.py:4).  ``init="device"``: the rebound function computes the NNDSVD start on
+    the GPU whenever the caller passes no ``init`` of its own (MANTA's pipelines never do, modeling_pipeline.py:62-67):
+    the host ``svds`` the reference uses takes 1-12 s on matrices whose whole factorisation takes 0.02-0.6 s here
+    (tools/e2e_small.py); the start then agrees with the reference's to ~1e-6 instead of bit for bit.
+    Returns the module names that were patched."""
+    import functools
     import importlib
+
+    target = run_nmf
+    if init is not None:
+        if init not in ("device", "device_random"):
+            raise ValueError("install(init=...): 'device' or 'device_random'")
+
+        @functools.wraps(run_nmf)
+        def target(num_of_topics, sparse_matrix, *args, **kw):
+            if not args:
+                kw.setdefault("init", init)
+            return run_nmf(num_of_topics, sparse_matrix, *args, **kw)
 
     patched = []
     if tfidf:
@@ -266,6 +282,6 @@ def install(tfidf: bool = False) -> list:
         except Exception:
             continue
         if hasattr(mod, "run_nmf"):
-            setattr(mod, "run_nmf", run_nmf)
+            setattr(mod, "run_nmf", target)
             patched.append(name)
     return patched

@@ -152,3 +152,39 @@ def test_random_device_init_and_run_nmf_strings():
             assert np.linalg.norm(dense - approx) < np.linalg.norm(dense)
     with pytest.raises(ValueError):
         manta_amd.run_nmf(5, X, init="nonsense")
+
+
+def test_device_svd_is_kept_for_the_resident_matrix(golden):
+    """The same matrix factorised again with the same topic count (methods compared, a run repeated): the right singular
+    vectors are kept per topic count and an exact repeat costs no iteration and returns the same triplets bit for bit;
+    another topic count is computed afresh (its result must not depend on earlier calls); replacing the matrix drops
+    everything kept."""
+    import torch
+    from manta_amd import init_device as idv
+    from manta_amd.engine import Engine
+
+    g = golden("fixed_B_1000x1200_k10")
+    eng = Engine(dtype="fp64")
+    try:
+        eng.set_matrix(g["X"])
+        info = {}
+        u8, s8, v8 = idv.truncated_svd_device(eng, 8, info=info)
+        assert info["steps"] > 0 and len(eng._svd_cache) == 1
+        info = {}
+        u8b, s8b, v8b = idv.truncated_svd_device(eng, 8, info=info)
+        assert info["steps"] == 0 and info.get("cached")
+        assert torch.equal(s8, s8b) and torch.equal(v8, v8b) and torch.equal(u8, u8b)
+        info = {}
+        u5, s5, v5 = idv.truncated_svd_device(eng, 5, info=info)
+        assert info["steps"] > 0 and not info.get("cached")
+        fresh = Engine(dtype="fp64")
+        try:
+            fresh.set_matrix(g["X"])
+            uf, sf, vf = idv.truncated_svd_device(fresh, 5)
+        finally:
+            fresh.close()
+        assert torch.equal(s5, sf) and torch.equal(v5, vf)       # independent of what was asked before
+        eng.set_matrix(g["X"])
+        assert not eng._svd_cache
+    finally:
+        eng.close()

@@ -320,6 +320,22 @@ def test_install_rebinds_run_nmf_where_manta_binds_it():
             assert sys.modules[n].run_nmf is manta_amd.run_nmf
         assert sys.modules["manta._functions.tfidf"].tf_idf_english is sentinel      # not asked for
         assert not hasattr(sys.modules["manta.pipeline"], "run_nmf")                   # nothing is added where nothing was bound
+        # install(init="device"): the rebound function fills in the GPU start only when the caller passes no init
+        manta_amd.install(init="device")
+        bound = sys.modules["manta.pipeline.modeling_pipeline"].run_nmf
+        assert bound is not manta_amd.run_nmf and bound.__wrapped__ is manta_amd.run_nmf
+        seen = {}
+        real = bound.__globals__["run_nmf"]
+        try:
+            bound.__globals__["run_nmf"] = lambda *a, **kw: seen.update(kw) or "ok"
+            assert bound(5, None, norm_thresh=0.005, nmf_method="nmf") == "ok" and seen["init"] == "device"
+            seen.clear()
+            assert bound(5, None, init=len) == "ok" and seen["init"] is len
+        finally:
+            bound.__globals__["run_nmf"] = real
+        with pytest.raises(ValueError):
+            manta_amd.install(init="host")
+        manta_amd.install()
         patched = manta_amd.install(tfidf=True)
         for n in with_tfidf:
             assert sys.modules[n].tf_idf_english is t.tf_idf_english and f"{n}.tf_idf_english" in patched
