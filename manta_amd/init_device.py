@@ -62,7 +62,7 @@ def _orthonormal_columns(Z, drop: bool = True):
     return Zq[:, good]
 
 
-def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = None, tol: float = 1e-10,
+def truncated_svd_device(eng, k: int, *, block: int | None = None, max_dim: int | None = None, tol: float = 1e-10,
                          seed: int = 0, max_steps: int = 2000, info: dict | None = None):
     """Leading ``k`` singular triplets (u: m x k, s: k, v: V x k, float64 device tensors, s descending) of the
     matrix resident in ``eng``.
@@ -76,6 +76,11 @@ def truncated_svd_device(eng, k: int, *, block: int = 16, max_dim: int | None = 
     if k < 1 or k > min(m, V):
         raise ValueError("k out of range")
     dev, dt = eng.device, eng.tdtype
+    if block is None:
+        # the number of steps hardly depends on the block width (it is the Krylov depth that converges), the cost of a
+        # step does: measured (tools/init_profile.py, tol 1e-10) k = 10 / 20 / 50: 0.13 / 0.25 / 0.76 s with 8 columns,
+        # 0.19 / 0.42 / 0.69 s with 16
+        block = 8 if k <= 32 else 16
     # The same matrix is factorised again with the same topic count when methods are compared or a run is repeated
     # with other thresholds: the engine keeps the right singular vectors per (k, tolerance, seed, block) of its resident
     # matrix (Engine.set_matrix drops them) and a repeated request costs one SpMM.  Only exact repeats are served --
