@@ -62,7 +62,7 @@ struct Tune {
   int xt_hot_words = 512;             // X^T: this many of the most frequent words go through LDS tiles of W
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 128;            // tile stream only if a tile holds at least this many documents (174-document tiles: X^T.W -10 % at k = 100 fp64; 93: +6 %)
-  int tile_min_tiles_pct = 75;        // ... and there are at least this many tiles, in percent of the CU count
+  int tile_min_tiles_pct = 60;        // ... and there are at least this many tiles, in percent of the CU count (64 %: X^T.W -15..-20 %; 38 %: +14 %)
   int ld_align_small = 0;             // padding of factor rows with k <= 32 (elements); 0 = whole 128-byte lines (32 floats /
                                       // 16 doubles): C4, k = 20: 80-byte rows -> 128-byte rows, +10 %; C1, k = 10: +17 %
   int pack_exchange = 1;              // sharded runs: all-reduce only the k live columns of ld-padded rows
