@@ -52,7 +52,8 @@ struct DevBuf {
 
 // Tunables (environment overrides are for experiments; defaults are what the benchmarks use).
 struct Tune {
-  int64_t x_q = 512;                  // target nnz per segment, X stream
+  int64_t x_q = 512;                  // target nnz per segment, X stream with the LDS-hot kernel (256: configs[1] X.H^T +4 %)
+  int64_t x_q_plain = 256;            // ... with the plain kernel (512: X.H^T +7..10 % at 1e7-2.5e7 nnz, equal elsewhere)
   int64_t xt_q = 128;                 // target nnz per segment, X^T stream (small: one XCD stays inside one document block)
   int64_t xt_block_bytes = 0;         // bytes of W rows per document block of X^T (upper limit; see spmm()); 0 = 4 MiB, 8 MiB at 32 lanes per row
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
@@ -69,6 +70,7 @@ struct Tune {
   int wide_gram = 1;                  // symmetric Grams with 128 < ld <= 256: tiles split over the waves of a workgroup
   int xt_min_piece = 4;               // X^T blocked stream: block a word only if df >= this many nnz per document block
   int kxk_chain = 1;                  // NMTF: the k x k products of an iteration in two launches instead of nine (ld <= 32)
+  int seg_target = 4096;              // shorten the segments of a stream until there are this many per lane group of a wave
   int side_prio = -1;                 // priority of the side stream: -1 low, 0 as the caller's stream, 1 high
   int xt_overlap = 1;                 // X^T.W: tile stream and blocked stream on two HIP streams at once
   int tile_threads = 0;               // threads of the tile kernel's workgroup (one per CU); 0: 512 beside the blocked
@@ -95,6 +97,7 @@ struct Tune {
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
     x_q = geti("MNMF_X_Q", x_q);
+    x_q_plain = geti("MNMF_X_Q_PLAIN", std::getenv("MNMF_X_Q") ? x_q : x_q_plain);
     xt_q = geti("MNMF_XT_Q", xt_q);
     xt_block_bytes = geti("MNMF_XT_BLOCK_BYTES", xt_block_bytes);
     xcd_affinity = (int)geti("MNMF_XCD_AFFINITY", xcd_affinity);
@@ -114,6 +117,7 @@ struct Tune {
     pack_exchange = (int)geti("MNMF_PACK_EXCHANGE", pack_exchange);
     xt_overlap = (int)geti("MNMF_XT_OVERLAP", xt_overlap);
     side_prio = (int)geti("MNMF_SIDE_PRIO", side_prio);
+    seg_target = (int)geti("MNMF_SEG_TARGET", seg_target);
     kxk_chain = (int)geti("MNMF_KXK_CHAIN", kxk_chain);
     tile_threads = (int)geti("MNMF_TILE_THREADS", tile_threads);
     if (tile_threads <= 0) tile_threads = xt_overlap ? 512 : 1024;
@@ -914,11 +918,12 @@ class Engine : public ImplBase {
 
   // part: 0 = everything, 1 = preparation (segments, carry buffer, zeroing of empty rows), 2 = kernels only
   int spmm_stream(StreamMat<T>& M, const T* B, int ld, T* out, int lpr, int vpl, int ng, int lds_ld, int part = 0) {
-    int64_t q = (&M == &Xt) ? tune.xt_q : (&M == &Xth) ? tune.xth_q : tune.x_q;
+    const bool x_hot = &M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= hot_x_threshold(lpr);
+    int64_t q = (&M == &Xt) ? tune.xt_q : (&M == &Xth) ? tune.xth_q : x_hot ? tune.x_q : tune.x_q_plain;
     if (&M == &Xth) {
       if (q <= 0) q = -(int64_t)(16 / tune.tile_wgs_per_cu * ng) * std::max<int64_t>(1, -q);  // equal split: (-xth_q) segments per lane group and tile
     } else {
-      while (q > 32 && M.nnz / q < (int64_t)4096 * ng) q >>= 1;
+      while (q > 32 && M.nnz / q < (int64_t)tune.seg_target * ng) q >>= 1;
       // the persistent LDS-hot kernel hands segments to n_cus x 16 waves: keep about six rounds of them, or the last
       // round's idle tail shows (measured on 1/8 and 1/4 shards of C2: X.H^T -13 % / -5 %)
       if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= hot_x_threshold(lpr))

@@ -15,3 +15,8 @@ for v in 2097152 8388608; do one MNMF_XT_BLOCK_BYTES=$v; done
 for v in 8 32; do one MNMF_LD_ALIGN=$v; done
 one MNMF_XT_OVERLAP=0
 one MNMF_XCD_AFFINITY=0
+one MNMF_PERMUTE_VOCAB=0
+one MNMF_XT_LONG_FLOOR=64
+one MNMF_XT_LONG_FLOOR=256
+one MNMF_XT_MIN_PIECE=2
+one MNMF_XT_MIN_PIECE=8
