@@ -54,7 +54,7 @@ struct DevBuf {
 struct Tune {
   int64_t x_q = 512;                  // target nnz per segment, X stream with the LDS-hot kernel (256: configs[1] X.H^T +4 %)
   int64_t x_q_plain = 256;            // ... with the plain kernel (512: X.H^T +7..10 % at 1e7-2.5e7 nnz, equal elsewhere)
-  int64_t xt_q = 128;                 // target nnz per segment, X^T stream (small: one XCD stays inside one document block)
+  int64_t xt_q = 0;                   // target nnz per segment, X^T blocked stream; 0 = 64 below 7e7 nnz, 128 above (X^T.W -2..7 % / +3 % across that line)
   int64_t xt_block_bytes = 0;         // bytes of W rows per document block of X^T (upper limit; see spmm()); 0 = 4 MiB, 8 MiB at 32 lanes per row
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
@@ -919,7 +919,8 @@ class Engine : public ImplBase {
   // part: 0 = everything, 1 = preparation (segments, carry buffer, zeroing of empty rows), 2 = kernels only
   int spmm_stream(StreamMat<T>& M, const T* B, int ld, T* out, int lpr, int vpl, int ng, int lds_ld, int part = 0) {
     const bool x_hot = &M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= hot_x_threshold(lpr);
-    int64_t q = (&M == &Xt) ? tune.xt_q : (&M == &Xth) ? tune.xth_q : x_hot ? tune.x_q : tune.x_q_plain;
+    const int64_t xt_q = tune.xt_q > 0 ? tune.xt_q : (nnz < 70000000 ? 64 : 128);
+    int64_t q = (&M == &Xt) ? xt_q : (&M == &Xth) ? tune.xth_q : x_hot ? tune.x_q : tune.x_q_plain;
     if (&M == &Xth) {
       if (q <= 0) q = -(int64_t)(16 / tune.tile_wgs_per_cu * ng) * std::max<int64_t>(1, -q);  // equal split: (-xth_q) segments per lane group and tile
     } else {
