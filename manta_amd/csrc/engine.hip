@@ -895,12 +895,13 @@ class Engine : public ImplBase {
     return 0;
   }
 
-  // Document block of the X^T blocked stream: 4 MiB of W rows (one XCD's L2) measured best at 128-, 256-, 832- and
-  // 896-byte rows; rows of 448-512 bytes (32 lanes per row: configs[2], fp64 configs[1]) gain 2-5 % on X^T.W with
-  // 8 MiB (tools/sweep_block.sh: 2.80 -> 2.66 ms, 3.23 -> 3.11 ms), the others lose 3 % or more there.
+  // Document block of the X^T blocked stream: 4 MiB of W rows (one XCD's L2) measured best at 128- and 256-byte rows
+  // (8 MiB: -3 %); rows of 448 bytes and more (32 and 64 lanes per row) gain 2-7 % on X^T.W with 8 MiB
+  // (tools/sweep_block.sh: configs[2] 2.80 -> 2.66 ms, fp64 configs[1] 3.23 -> 3.11 ms, k = 200 5.37 -> 4.97 ms,
+  // configs[4] shard 15.8 -> 15.1 ms); 16 MiB loses everywhere.
   int64_t xt_block_limit(int lpr) const {
     if (tune.xt_block_bytes > 0) return tune.xt_block_bytes;
-    return lpr == 32 ? (int64_t)8 << 20 : (int64_t)4 << 20;
+    return lpr >= 32 ? (int64_t)8 << 20 : (int64_t)4 << 20;
   }
 
   // Smallest X (nnz) for which X.H^T takes the LDS-hot kernel rather than the plain stream kernel, by lanes per factor
