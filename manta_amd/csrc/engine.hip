@@ -60,7 +60,7 @@ struct Tune {
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
   int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
-  int xt_hot_words = -1;              // X^T: this many of the most frequent words go through LDS tiles of W (0: none; -1: 512, 256 when a tile holds fewer than 256 documents)
+  int xt_hot_words = -1;              // X^T: this many of the most frequent words go through LDS tiles of W (0: none; -1: 512; 256 when a tile holds fewer than 256 documents, 1024 from 1024)
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 128;            // tile stream only if a tile holds at least this many documents (174-document tiles: X^T.W -10 % at k = 100 fp64; 93: +6 %)
   int tile_min_tiles_pct = 60;        // ... and there are at least this many tiles, in percent of the CU count (64 %: X^T.W -15..-20 %; 38 %: +14 %)
@@ -811,7 +811,8 @@ class Engine : public ImplBase {
         // every (tile, hot word) pair is a carry row: with wide rows (few documents per tile, many tiles) half as many
         // hot words cost less in carries than they lose in LDS gathers (832-byte rows: X^T.W 17.4 -> 15.8 ms at the
         // configs[4] shard; 448-512-byte rows: equal)
-        const int hot_words = tune.xt_hot_words > 0 ? tune.xt_hot_words : (tile_rows < 256 ? 256 : 512);
+        // ... and with 128-byte rows (1218 documents per tile) twice as many pay: X^T.W -2..4 % at configs[3] and its parts
+        const int hot_words = tune.xt_hot_words > 0 ? tune.xt_hot_words : (tile_rows < 256 ? 256 : tile_rows >= 1024 ? 1024 : 512);
         n_hot = (int)std::min<int64_t>(hot_words, V / 2);
         // worth it only with long pieces (enough documents per tile: fewer carries than gathers saved; measured
         // beside the blocked stream C2 +10 %, C4 +8 %, C3 with 344-document tiles +6 %) and enough tiles to
