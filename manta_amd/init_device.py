@@ -63,6 +63,7 @@ def _orthonormal_columns(Z, drop: bool = True):
 
 
 def truncated_svd_device(eng, k: int, *, block: int | None = None, max_dim: int | None = None, tol: float = 1e-10,
+                         rr_every: int = 3,
                          seed: int = 0, max_steps: int = 2000, info: dict | None = None):
     """Leading ``k`` singular triplets (u: m x k, s: k, v: V x k, float64 device tensors, s descending) of the
     matrix resident in ``eng``.
@@ -85,7 +86,7 @@ def truncated_svd_device(eng, k: int, *, block: int | None = None, max_dim: int 
     # with other thresholds: the engine keeps the right singular vectors per (k, tolerance, seed, block) of its resident
     # matrix (Engine.set_matrix drops them) and a repeated request costs one SpMM.  Only exact repeats are served --
     # slicing or warm-starting from another k's vectors would make a result depend on the calls that came before it.
-    ckey = (k, float(tol), int(seed), int(block), max_dim)
+    ckey = (k, float(tol), int(seed), int(block), max_dim, int(rr_every))
     cache = getattr(eng, "_svd_cache", None)
     hit = cache.get(ckey) if isinstance(cache, dict) else None
     if hit is not None and hit["v"].shape[0] == V and hit["v"].device == dev:
@@ -124,6 +125,14 @@ def truncated_svd_device(eng, k: int, *, block: int | None = None, max_dim: int 
         Tn[:, old:] = C
         Tn[old:, :old] = C[:old].t()
         T = Tn
+        # Between two Rayleigh-Ritz steps the basis grows by the plain block Lanczos vector -- A.Vj orthogonalised
+        # against everything so far, the same new directions the residual block would bring -- which needs no
+        # eigen-decomposition, no residuals and no trip to the host (rr_every - 1 of every rr_every steps).
+        if rr_every > 1 and steps % rr_every != 0 and dim + 2 * b <= max_dim and dim + b < V and steps < max_steps:
+            Vn = orth_against(Z, Q)
+            if Vn.shape[1] > 0:
+                Vj = Vn
+                continue
         # Rayleigh-Ritz on the host: the projected matrix has a few hundred rows at most, LAPACK takes 0.3-0.7 ms
         # including both copies where the device solver takes 1.6 ms (measured at dim = 100) -- half of a step
         ev_h, evec_h = torch.linalg.eigh((0.5 * (T + T.t())).cpu())

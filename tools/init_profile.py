@@ -10,14 +10,14 @@ for (M, V, dens, K) in [(20_000, 30_000, 0.003, 10), (100_000, 50_000, 0.002, 20
     for dtype in ("fp64",):
         eng = N._engine(dtype, None)
         eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(M, V))
-        for block in (2, 4, 8):
-            for max_dim in (None,):
+        for block in (8, 16):
+            for rr in (1, 2, 3):
                 info = {}
-                kw = dict(info=info, block=block, max_dim=max_dim, seed=1)
+                kw = dict(info=info, block=block, rr_every=rr, seed=1)
                 eng._svd_cache = None
                 idv.truncated_svd_device(eng, K, **dict(kw, info={}, seed=2))
                 torch.cuda.synchronize(); t = time.time()
                 u, s, v = idv.truncated_svd_device(eng, K, **kw)
                 torch.cuda.synchronize(); dt = time.time() - t
-                print(f"{M}x{V} k={K} {dtype} block={block} max_dim={max_dim}: {dt:.3f} s, steps {info['steps']}, restarts {info['restarts']}, "
+                print(f"{M}x{V} k={K} {dtype} block={block} rr_every={rr}: {dt:.3f} s, steps {info['steps']}, restarts {info['restarts']}, "
                       f"{dt / max(info['steps'], 1) * 1e3:.2f} ms/step", flush=True)
