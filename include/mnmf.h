@@ -160,6 +160,10 @@ int mnmf_update(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* n
  * calls ordered on one stream do not.  Nothing in the array has to be zero on entry.  Summation order differs from
  * mnmf_gram's (fp32: vector ALUs here, matrix cores there): results agree to rounding, not bit for bit. */
 int mnmf_gram_static(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, void* out);
+/* Diagnostic, no counterpart in the reference: how many device / pinned-host allocations (hipMalloc, hipHostMalloc)
+ * the library has made in this process so far, over all contexts.  tests/test_zz_no_alloc.py reads it before and after
+ * mnmf_gram_static. */
+int64_t mnmf_alloc_count(void);
 /* sigma_max(|A - B|) (norm_kind 0, `norm_func(np.abs(w - w_old), 2)`, nmf_basic.py:52) or its
  * Frobenius norm (norm_kind 1, nmtf.py:179) for rows x k matrices. */
 int mnmf_diff_norm(mnmf_ctx* ctx, int64_t rows, int k, const void* A, const void* B, int norm_kind,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mnmf_destroy": (None, [C.c_void_p]),
     "mnmf_last_error": (C.c_char_p, [C.c_void_p]),
     "mnmf_version": (C.c_char_p, []),
+    "mnmf_alloc_count": (C.c_int64, []),
     "mnmf_row_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "mnmf_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]),
     "mnmf_set_comm": (C.c_int, [C.c_void_p, COMM_FN, C.c_void_p, C.c_int, C.c_int]),

@@ -65,6 +65,8 @@ extern "C" {
 
 const char* mnmf_version(void) { return "mnmf 0.1 (gfx950)"; }
 
+int64_t mnmf_alloc_count(void) { return (int64_t)g_mnmf_allocs.load(std::memory_order_relaxed); }
+
 int mnmf_create(mnmf_ctx** out, int device, int dtype, void* hip_stream) {
   if (!out || (dtype != MNMF_F32 && dtype != MNMF_F64)) return MNMF_EINVAL;
   *out = nullptr;

@@ -320,7 +320,8 @@ __global__ void s_confusion_kernel(const T* __restrict__ S, int k, int lds, int3
     v = S[i];
     for (int r = 1; r < k; ++r) {
       const T x = S[(int64_t)r * lds + i];
-      if (x > v) {
+      // np.argmax (nmtf.py:69): the first NaN of a column wins, and nothing replaces it
+      if (x > v || (x != x && v == v)) {
         v = x;
         arg = r;
       }
@@ -332,7 +333,12 @@ __global__ void s_confusion_kernel(const T* __restrict__ S, int k, int lds, int3
     int rank = 0;
     for (int j = 0; j < k; ++j) {
       const T x = best[j];
-      rank += (x > v || (x == v && j > i)) ? 1 : 0;
+      // np.argsort(...)[::-1] (nmtf.py:73): NaN ranks as the greatest value; equal values (two NaNs included) put the
+      // larger column first -- a total order, so every rank is written exactly once
+      const bool xn = x != x, vn = v != v;
+      const bool greater = (xn && !vn) || (!xn && !vn && x > v);
+      const bool equal = (xn && vn) || (!xn && !vn && x == v);
+      rank += (greater || (equal && j > i)) ? 1 : 0;
     }
     col_out[rank] = i;
     row_out[rank] = arg;

@@ -42,7 +42,7 @@ struct DevBuf {
     if (bytes <= cap) return hipSuccess;
     release();
     if (bytes == 0) return hipSuccess;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = mnmf_counted_malloc(&p, bytes);
     if (e == hipSuccess) cap = bytes; else p = nullptr;
     return e;
   }
@@ -272,6 +272,7 @@ class Engine : public ImplBase {
     if (h_pinned) (void)hipHostFree(h_pinned);
     h_pinned = nullptr;
     h_pinned_cap = 0;
+    g_mnmf_allocs.fetch_add(1, std::memory_order_relaxed);
     E_HIP(hipHostMalloc((void**)&h_pinned, doubles * sizeof(double), hipHostMallocDefault));
     h_pinned_cap = doubles;
     return 0;

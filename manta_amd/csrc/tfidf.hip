@@ -213,7 +213,7 @@ int mnmf_tfidf_count_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* d
   if (m == 0) return MNMF_OK;
   MNMF_HIP_TRY(ctx, hipSetDevice(ctx->device));
   int* flags = nullptr;
-  MNMF_HIP_TRY(ctx, hipMalloc(&flags, sizeof(int)));
+  MNMF_HIP_TRY(ctx, mnmf_counted_malloc((void**)&flags, sizeof(int)));
   int rc = MNMF_OK, h = 0;
   if (hipMemsetAsync(flags, 0, sizeof(int), ctx->stream) != hipSuccess) rc = MNMF_EHIP;
   if (rc == 0) rc = launch_doc_terms(ctx, m, V, doc_ptr, tokens, row_nnz, ws_cols, ws_counts, flags);
@@ -254,7 +254,7 @@ int mnmf_tfidf_fill_terms(mnmf_ctx* ctx, int64_t m, int64_t V, const int64_t* do
   // document frequencies: histogram over the distinct (document, word) pairs (histogram.hpp)
   const int copies = hist_copies(V);
   int32_t* parts = nullptr;
-  if (rc == 0 && hipMalloc(&parts, (size_t)copies * V * 4) != hipSuccess) {
+  if (rc == 0 && mnmf_counted_malloc((void**)&parts, (size_t)copies * V * 4) != hipSuccess) {
     ctx->fail(MNMF_EHIP, "mnmf_tfidf_fill_terms: out of device memory");
     rc = MNMF_EHIP;
   }

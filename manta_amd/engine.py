@@ -3,6 +3,7 @@ torch.distributed; every numeric step runs in libmnmf.so (HIP)."""
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -48,6 +49,25 @@ def _opts(max_iter=-1, fixed_iters=0, check_every=1, force_check=False, finalize
     o.eps = float(eps)
     o.zero_threshold = float(zero_threshold)
     return o
+
+
+def _engine_stream(fn):
+    """Run a method with the engine's stream as torch's current one.  The library enqueues its kernels on the stream
+    captured when the Engine was created; the torch side of a call (uploads, clones, output buffers, the collectives of
+    the hook) must be ordered on the same stream, whatever stream the caller happens to be under.  The caller's stream
+    waits for the engine's before the method returns."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream.cuda_stream:
+            return fn(self, *a, **kw)
+        self.stream.wait_stream(cur)
+        try:
+            with torch.cuda.stream(self.stream):
+                return fn(self, *a, **kw)
+        finally:
+            cur.wait_stream(self.stream)
+    return wrapped
 
 
 class Engine:
@@ -110,6 +130,7 @@ class Engine:
                      flops_model=s.flops_model, phase_ms={n: s.phase_ms[i] for i, n in enumerate(PHASES)})
 
     # ------------------------------------------------------------------ matrix
+    @_engine_stream
     def set_matrix(self, X=None, *, rowptr=None, colidx=None, vals=None, shape=None):
         """``X``: a scipy sparse matrix (host), or give device/host tensors ``rowptr`` (int64), ``colidx``
         (int32), ``vals`` and ``shape``.  The engine copies and keeps X and X^T resident."""
@@ -201,9 +222,17 @@ class Engine:
             else:
                 mine.copy_(host[rank * count:(rank + 1) * count])
 
+        def on_engine_stream(stream_ptr):
+            # include/mnmf.h: the collective is ordered against `stream`, the one the engine enqueues its kernels on --
+            # not against whatever stream happens to be torch's current one when the solver is called
+            sp = int(stream_ptr or 0)
+            st = torch.cuda.ExternalStream(sp, device=eng.device) if sp else torch.cuda.default_stream(eng.device)
+            return torch.cuda.stream(st)
+
         def comm_hook(_user, op, ptr, count, _dtype, _stream):
             try:
-                run(int(op), ptr, int(count))
+                with on_engine_stream(_stream):
+                    run(int(op), ptr, int(count))
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 print(f"[manta_amd] collective hook failed: {e!r}", flush=True)
@@ -211,7 +240,8 @@ class Engine:
 
         def ar_hook(_user, ptr, count, _dtype, _stream):
             try:
-                run(_lib.COMM_ALLREDUCE, ptr, int(count))
+                with on_engine_stream(_stream):
+                    run(_lib.COMM_ALLREDUCE, ptr, int(count))
                 return 0
             except Exception as e:
                 print(f"[manta_amd] all-reduce hook failed: {e!r}", flush=True)
@@ -227,6 +257,7 @@ class Engine:
             self._check(self._lib.mnmf_set_allreduce(self._h, self._hook, None, world))
 
     # ------------------------------------------------------------------ solvers
+    @_engine_stream
     def run_nmf(self, W0, H0, **kw):
         W, H = self._dev(W0).clone(), self._dev(H0).clone()
         k = W.shape[1]
@@ -236,6 +267,7 @@ class Engine:
         self._check(self._lib.mnmf_run_nmf(self._h, k, W.data_ptr(), H.data_ptr(), C.byref(o), C.byref(s)))
         return W, H, self._stats(s)
 
+    @_engine_stream
     def run_nmf_sweep(self, W0s, H0s, **kw):
         """Standard NMF for several topic counts in one pass over X per SpMM (mnmf_run_nmf_sweep): ``W0s[p]`` is
         m x k_p, ``H0s[p]`` is k_p x V, the k_p of one call add up to at most 32 (fp32).  Returns a list of
@@ -257,6 +289,7 @@ class Engine:
         self._check(self._lib.mnmf_run_nmf_sweep(self._h, n, ks_c, wp, hp, C.byref(o), st))
         return [(Ws[p], Hs[p], self._stats(st[p])) for p in range(n)]
 
+    @_engine_stream
     def run_pnmf(self, W0, **kw):
         W = self._dev(W0).clone()
         k = W.shape[1]
@@ -267,6 +300,7 @@ class Engine:
         self._check(self._lib.mnmf_run_pnmf(self._h, k, W.data_ptr(), H.data_ptr(), C.byref(o), C.byref(s)))
         return W, H, self._stats(s)
 
+    @_engine_stream
     def run_nmtf(self, W0, S0, H0, **kw):
         W, S, H = self._dev(W0).clone(), self._dev(S0).clone(), self._dev(H0).clone()
         k = W.shape[1]
@@ -277,6 +311,7 @@ class Engine:
         return W, S, H, self._stats(s)
 
     # ------------------------------------------------------------------ kernel-level
+    @_engine_stream
     def spmm(self, B, transpose=False):
         B = self._dev(B)
         k = B.shape[1]
@@ -287,6 +322,7 @@ class Engine:
         self._check(self._lib.mnmf_spmm(self._h, int(bool(transpose)), k, B.data_ptr(), out.data_ptr()))
         return out
 
+    @_engine_stream
     def gram(self, A, B=None):
         A = self._dev(A)
         rows, k = A.shape
@@ -300,6 +336,7 @@ class Engine:
         self._check(self._lib.mnmf_gram(self._h, rows, k, A.data_ptr(), Bp, out.data_ptr()))
         return out
 
+    @_engine_stream
     def update(self, A, num, G, G2=None, eps=1e-10, sqrt_mode=False):
         A, num, G = self._dev(A), self._dev(num), self._dev(G)
         rows, k = A.shape
@@ -314,6 +351,7 @@ class Engine:
                                           float(eps), int(bool(sqrt_mode)), out.data_ptr()))
         return out
 
+    @_engine_stream
     def topk(self, A, n, by_column=False):
         """The ``n`` largest entries of every row (or column) of ``A``, descending, ties: larger index first.
         Returns (indices int32 [groups, n], values [groups, n]) as device tensors."""
@@ -337,6 +375,7 @@ class Engine:
             words = words[rows]
         return words, docs
 
+    @_engine_stream
     def s_matrix_confusion(self, S, console=None):
         """The NMTF topic-relationship summary of ``s_matrix_confusion`` (nmtf/nmtf.py:62-80) computed where S lives:
         per column of S its strongest row (``np.argmax``) and that strength, strongest coupling first.  Returns
@@ -347,9 +386,9 @@ class Engine:
         k = S.shape[0]
         if S.shape != (k, k):
             raise ValueError("S must be square")
-        col = torch.empty(k, dtype=torch.int32, device=self.device)
-        row = torch.empty(k, dtype=torch.int32, device=self.device)
-        val = torch.empty(k, dtype=self.tdtype, device=self.device)
+        col = torch.full((k,), -1, dtype=torch.int32, device=self.device)
+        row = torch.full((k,), -1, dtype=torch.int32, device=self.device)
+        val = torch.full((k,), float("nan"), dtype=self.tdtype, device=self.device)
         self._check(self._lib.mnmf_s_confusion(self._h, k, S.data_ptr(), col.data_ptr(), row.data_ptr(), val.data_ptr()))
         cols, rows, vals = col.cpu().numpy(), row.cpu().numpy(), val.cpu().double().numpy()
         if console is not None:
@@ -381,6 +420,7 @@ class Engine:
         idx, val = eng.topk(masked.contiguous(), top_n)
         return torch.where(torch.isinf(val), torch.full_like(idx, -1), idx), val
 
+    @_engine_stream
     def diff_norm(self, A, B, kind="spectral"):
         A, B = self._dev(A), self._dev(B)
         if A.shape != B.shape:

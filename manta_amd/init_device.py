@@ -178,10 +178,31 @@ def truncated_svd_device(eng, k: int, *, block: int | None = None, max_dim: int 
     if converged:
         if not isinstance(getattr(eng, "_svd_cache", None), dict):
             eng._svd_cache = {}
-        if len(eng._svd_cache) >= 8:                              # a handful of V x k matrices at most
-            eng._svd_cache.pop(next(iter(eng._svd_cache)))
-        eng._svd_cache[ckey] = dict(v=v, residual=float(rn.max() / theta[0]))
+        # capped by BYTES (MANTA_AMD_SVD_CACHE_MB, default 256; 0 disables): at V = 500k, k = 200 one entry is 0.8 GB,
+        # and a topic-count sweep fills the cache with entries it never reads again (the keys differ by k)
+        limit = svd_cache_limit_bytes()
+        size = v.numel() * v.element_size()
+        if size <= limit:
+            def held():
+                return sum(e["v"].numel() * e["v"].element_size() for e in eng._svd_cache.values())
+            while eng._svd_cache and (len(eng._svd_cache) >= 8 or held() + size > limit):
+                eng._svd_cache.pop(next(iter(eng._svd_cache)))    # oldest first
+            eng._svd_cache[ckey] = dict(v=v, residual=float(rn.max() / theta[0]))
     return _triplets_from_v(eng, v, k)
+
+
+def svd_cache_limit_bytes() -> int:
+    """Bytes of right singular vectors an engine may keep between calls (env MANTA_AMD_SVD_CACHE_MB, default 256)."""
+    import os
+    try:
+        return max(0, int(float(os.environ.get("MANTA_AMD_SVD_CACHE_MB", "256")) * (1 << 20)))
+    except ValueError:
+        return 256 << 20
+
+
+def clear_svd_cache(eng) -> None:
+    """Drop the singular vectors kept for the resident matrix (Engine.set_matrix does the same)."""
+    eng._svd_cache = None
 
 
 def _triplets_from_v(eng, v, k):

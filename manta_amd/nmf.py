@@ -187,16 +187,21 @@ def sweep_batches(ks, limit=SWEEP_LINE):
 def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initialization_nndsvd, norm_thresh=0.001,
                   zero_threshold=0.00001, nmf_method: str = "nmf", *, dtype: Optional[str] = None, device=None,
                   max_iter: Optional[int] = None, fixed_iters: Optional[int] = None, check_every: int = 1,
-                  starts=None, stats_out: Optional[list] = None) -> list:
+                  starts=None, seed: int = 0, stats_out: Optional[list] = None) -> list:
     """``[run_nmf(k, sparse_matrix, ...) for k in topic_counts]`` -- the loop of OptimizationPipeline.run_optimization
     (optimization_pipeline.py:105-136, 193-198) -- with the matrix uploaded once and, for standard NMF in fp32, the
     topic counts that fit one padded factor row (sum <= 32) iterated TOGETHER: one pass over X per SpMM serves the
     whole batch.  Every entry of the returned list equals the single ``run_nmf`` call bit for bit (same start).
 
     ``starts``: optional list of ``(W0, H0)`` per topic count; otherwise ``init`` is called once per count, in order,
-    as the reference's loop would.  Other methods, fp64 and counts that do not fit a batch run one by one."""
+    as the reference's loop would (``init="device"`` / ``"device_random"`` as in ``run_nmf``: the starts are then
+    computed on the resident matrix, ``seed`` feeding the random one).  Other methods and counts that do not fit a
+    batch run one by one."""
     ks = [int(k) for k in topic_counts]
     dtype = dtype or os.environ.get("MANTA_AMD_DTYPE", "fp64")
+    device_init = isinstance(init, str)
+    if device_init and init not in ("device", "device_random"):
+        raise ValueError("init must be a callable (csc, rank) -> (W0, H0) or one of the strings 'device', 'device_random'")
     results = [None] * len(ks)
     stats = [dict() for _ in ks]
     batched = nmf_method == "nmf" and dtype == "fp32" and all(k > 0 for k in ks)
@@ -208,14 +213,20 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
     if fixed_iters:
         extra["fixed_iters"] = fixed_iters
     if batched:
-        csc = sparse_matrix.tocsc() if starts is None else None
-        if starts is None:
+        csc = sparse_matrix.tocsc() if (starts is None and not device_init) else None
+        if starts is None and not device_init:
             starts = [init(csc, k) for k in ks]                            # nmf_orchestrator.py:109, once per call
         key = _matrix_key(sparse_matrix)
         eng = _engine(dtype, device)
         if key is None or eng._resident_key != key:
             eng.set_matrix((csc if csc is not None else sparse_matrix).tocsr())
             eng._resident_key = key
+        if starts is None:                                                 # device starts, on the matrix now resident
+            from . import init_device as idv
+            if init == "device_random":
+                starts = [idv.random_device(eng, k, seed=seed, with_s=True)[::2] for k in ks]   # run_nmf's draw: W, (S), H
+            else:
+                starts = [idv.nndsvd_device(eng, k) for k in ks]
         for batch in sweep_batches(ks):
             if len(batch) == 1:
                 i = batch[0]
@@ -233,7 +244,7 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
             kw = {} if starts is None else dict(W0=starts[i][0], H0=starts[i][1])
             results[i] = run_nmf(k, sparse_matrix, init=init, norm_thresh=norm_thresh, zero_threshold=zero_threshold,
                                  nmf_method=nmf_method, dtype=dtype, device=device, max_iter=max_iter,
-                                 fixed_iters=fixed_iters, check_every=check_every, stats_out=stats[i], **kw)
+                                 fixed_iters=fixed_iters, check_every=check_every, seed=seed, stats_out=stats[i], **kw)
     if stats_out is not None:
         stats_out[:] = stats
     return results

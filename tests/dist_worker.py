@@ -163,8 +163,26 @@ def main():
         kw = dict(fixed_iters=N, zero_threshold=0.0) if method != "pnmf" else dict(fixed_iters=N)
         if len(sys.argv) > 4 and sys.argv[4] == "check":      # with the convergence Grams exchanged every iteration
             kw["force_check"] = True
-        res = run_sharded(method, Xl, W0[lo:hi], H0, S0, dtype=dtype, device=0, collectives=(mode != "engine_ar"),
-                          single_rank_hook=mode.startswith("nccl1"), **kw)
+        if mode.endswith("_stream"):
+            # "nccl1_stream": the engine lives on the stream it was created under (the default one); the solver is then
+            # called under ANOTHER torch stream -- uploads, the hook's collectives and the engine's kernels must still be
+            # ordered (Engine runs its torch side on its own stream, the hook on the stream the library hands it)
+            from manta_amd.engine import Engine
+            eng = Engine(device=0, dtype=dtype)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng.set_matrix(Xl)
+                eng.set_process_group(None, collectives=True, single_rank_hook=True)
+                if method == "nmf":
+                    res = eng.run_nmf(W0[lo:hi], H0, **kw)
+                elif method == "pnmf":
+                    res = eng.run_pnmf(W0[lo:hi], **kw)
+                else:
+                    res = eng.run_nmtf(W0[lo:hi], S0, H0, **kw)
+                res = tuple(r.clone() if isinstance(r, torch.Tensor) else r for r in res)
+            eng.close()
+        else:
+            res = run_sharded(method, Xl, W0[lo:hi], H0, S0, dtype=dtype, device=0, collectives=(mode != "engine_ar"),
+                              single_rank_hook=mode.startswith("nccl1"), **kw)
         keys = ["W", "S", "H"] if method == "nmtf" else ["W", "H"]
         got = {k_: v.cpu().double().numpy() for k_, v in zip(keys, res[:-1])}
         tol = 1e-10 if dtype == "fp64" else 1e-4

@@ -100,6 +100,14 @@ def test_rccl_calls_in_a_group_of_one(method, dtype):
 
 
 @pytest.mark.gpu
+def test_solver_called_under_another_torch_stream():
+    """Engine created on the default stream, solver (with the RCCL hook of a group of one) called under a side stream:
+    the torch side of the call and the hook's collectives run on the engine's stream, so the result is still the
+    oracle's."""
+    launch(["nccl1_stream", "nmf", "fp32", "check"], 29671, nproc=1, MNMF_RS_AG="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+@pytest.mark.gpu
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (how the driver starts --gpus 1) must start its ranks as a
     child torch.distributed.run and print one JSON line with n_gpus = 2.  Two ranks share the one GPU here, so the

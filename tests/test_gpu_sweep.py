@@ -111,3 +111,22 @@ def test_run_nmf_sweep_drop_in_groups_and_falls_back(golden):
         assert s["iters"] == one["iters"]
     got = manta_amd.run_nmf_sweep(X, [4, 6], norm_thresh=0.005, nmf_method="pnmf", dtype="fp64", starts=starts_for(X, [4, 6], 6))
     assert [o["W"].shape[1] for o in got] == [4, 6]
+
+
+@pytest.mark.parametrize("init", ["device", "device_random"])
+def test_run_nmf_sweep_with_device_starts(golden, init):
+    """``init`` as a string on the batched path: the starts come from the resident matrix (init_device), once per topic
+    count, and every result equals the single run_nmf call with the same ``init`` (and ``seed``) bit for bit."""
+    import manta_amd
+
+    g = golden("converged_D_600x500_k6_nmf")
+    X = g["X"]
+    ks = [4, 6, 9]
+    stats = []
+    got = manta_amd.run_nmf_sweep(X, ks, init=init, norm_thresh=0.005, dtype="fp32", seed=3, stats_out=stats)
+    assert [s["batch"] for s in stats] == [ks] * 3
+    for k, out in zip(ks, got):
+        want = manta_amd.run_nmf(k, X, init=init, norm_thresh=0.005, dtype="fp32", seed=3)
+        assert np.array_equal(out["W"], want["W"]) and np.array_equal(out["H"], want["H"])
+    with pytest.raises(ValueError):
+        manta_amd.run_nmf_sweep(X, ks, init="host", dtype="fp32")

@@ -124,3 +124,29 @@ def test_s_matrix_confusion_matches_reference_lines(dtype):
             assert np.allclose(vals, o_vals, rtol=1e-6)
             assert len(rec.lines) == S.shape[1] and rec.lines == confusion_lines(rows, vals)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_s_matrix_confusion_nan_and_tied_columns():
+    """A NaN in S (np.argmax takes the first NaN of a column, np.argsort ranks NaN above every number) and columns with
+    equal maxima: every rank is written exactly once and the order is numpy's (nmtf.py:69, 73).  Ties between equal
+    values are not pinned by the reference (np.argsort is not stable): checked as sets there."""
+    from manta_amd.engine import Engine
+
+    eng = Engine(device=0, dtype="fp64")
+    rng = np.random.default_rng(3)
+    S = rng.random((7, 7))
+    S[2, 1] = np.nan                 # column 1: best value NaN, row 2
+    S[5, 1] = np.nan
+    S[4, 6] = np.nan                 # a second NaN column
+    S[:, 3] = S[:, 0]                # tied columns 0 and 3
+    cols, rows, vals = eng.s_matrix_confusion(S)
+    o_cols, o_rows, o_vals, _ = oc.s_matrix_confusion(S)
+    assert sorted(cols.tolist()) == list(range(7))           # a permutation: no slot written twice, none left out
+    assert set(cols[:2].tolist()) == {1, 6} and np.isnan(vals[:2]).all()
+    assert rows[list(cols).index(1)] == 2 and rows[list(cols).index(6)] == 4
+    assert np.array_equal(vals[2:], o_vals[2:])
+    assert np.array_equal(rows[2:][np.argsort(cols[2:])], o_rows[2:][np.argsort(o_cols[2:])])
+    tied = [i for i, c in enumerate(cols) if c in (0, 3)]
+    assert tied[1] == tied[0] + 1 and vals[tied[0]] == vals[tied[1]]
+    eng.close()
