@@ -94,6 +94,7 @@ struct Tune {
   int mfma_f64 = 1;                   // fp64 update + fused Grams on the matrix cores (k <= 64)
   int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
+  int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
     x_q = geti("MNMF_X_Q", x_q);
@@ -130,6 +131,7 @@ struct Tune {
     lds_pad = (int)geti("MNMF_LDS_PAD", lds_pad);
     xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
+    two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
     rs_ag = (int)geti("MNMF_RS_AG", rs_ag);
     mfma_f64 = (int)geti("MNMF_MFMA_F64", mfma_f64);
     rk_one_pass = (int)geti("MNMF_RK_ONE_PASS", rk_one_pass);
@@ -185,7 +187,7 @@ struct StreamMat {
   // segment description for the current seg_q
   int64_t seg_q = -1, n_seg = 0, n_dest = 0, n_empty = 0, n_fix = 0, n_fix_long = 0, n_carry = 0;
   int seg_group = -1;
-  DevBuf seg_start, seg_len, seg_info, dest, empty_rows, fix_row, fix_first, fix_count, carry;
+  DevBuf seg_desc, dest, empty_rows, fix_row, fix_first, fix_count, carry;
 };
 
 // the sweep stream of X^T (rare words; spmm.hpp: spmm_sweep_kernel)
@@ -317,8 +319,8 @@ class Engine : public ImplBase {
     Xth.tab_rows = m;
     Xth.nnz = 0;
     const size_t n = (size_t)std::max<int64_t>(nnz, 1);
-    E_HIP(X.cols.ensure(n * 4));
-    E_HIP(X.vals.ensure(n * sizeof(T)));
+    E_HIP(X.cols.ensure((n + kStreamPad) * 4));   // the SpMM kernels fetch whole chunks: slack behind the last nnz
+    E_HIP(X.vals.ensure((n + kStreamPad) * sizeof(T)));
     E_HIP(d_rowptr.ensure((m + 1) * 8));
     pieces_from_rowptr(h_rowptr.data(), m, X.pieces);
     X.built = true;
@@ -481,10 +483,10 @@ class Engine : public ImplBase {
       E_HIP(hipStreamSynchronize(st()));
       n_hot_nnz = h;
     }
-    E_HIP(Xt.cols.ensure(std::max<size_t>(n - (size_t)n_hot_nnz, 1) * 4));
-    E_HIP(Xt.vals.ensure(std::max<size_t>(n - (size_t)n_hot_nnz, 1) * sizeof(T)));
-    E_HIP(Xth.cols.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * 4));
-    E_HIP(Xth.vals.ensure(std::max<size_t>((size_t)n_hot_nnz, 1) * sizeof(T)));
+    E_HIP(Xt.cols.ensure((n - (size_t)n_hot_nnz + kStreamPad) * 4));
+    E_HIP(Xt.vals.ensure((n - (size_t)n_hot_nnz + kStreamPad) * sizeof(T)));
+    E_HIP(Xth.cols.ensure(((size_t)n_hot_nnz + kStreamPad) * 4));
+    E_HIP(Xth.vals.ensure(((size_t)n_hot_nnz + kStreamPad) * sizeof(T)));
     // a word is cut at document-block boundaries only if its pieces stay long enough to pay for their carry slots
     const int32_t long_df = (int32_t)std::min<int64_t>(std::max<int64_t>(tune.xt_long_floor, (int64_t)tune.xt_min_piece * n_blocks), 1 << 30);
     // ---- sweep stream of the rare words (not cut at document blocks: df <= long_df)
@@ -685,9 +687,12 @@ class Engine : public ImplBase {
       s.fix_first.swap(f);
       s.fix_count.swap(c);
     }
-    MNMF_TRY(upload(M.seg_start, s.seg_start.data(), s.seg_start.size() * 8));
-    MNMF_TRY(upload(M.seg_len, s.seg_len.data(), s.seg_len.size() * 4));
-    MNMF_TRY(upload(M.seg_info, s.seg_info.data(), s.seg_info.size() * 4));
+    {  // one 16-byte descriptor per segment: a lane group fetches it with a single load
+      std::vector<SegDesc> sd((size_t)s.n_seg());
+      for (size_t i = 0; i < sd.size(); ++i) sd[i] = SegDesc{s.seg_start[i], s.seg_len[i], s.seg_info[i]};
+      MNMF_TRY(upload(M.seg_desc, sd.data(), sd.size() * sizeof(SegDesc)));
+    }
+    s.dest.resize(s.dest.size() + kStreamPad, 0);   // the kernels fetch whole chunks of the list
     MNMF_TRY(upload(M.dest, s.dest.data(), s.dest.size() * 4));
     MNMF_TRY(upload(M.empty_rows, s.empty_rows.data(), s.empty_rows.size() * 4));
     MNMF_TRY(upload(M.fix_row, s.fix_row.data(), s.fix_row.size() * 4));
@@ -718,7 +723,7 @@ class Engine : public ImplBase {
     const bool wide = tune.force_wide || M.tab_rows >= ((int64_t)1 << 24) || tab_bytes >= ((size_t)1 << 32) ||
                       (size_t)ld * sizeof(T) >= ((size_t)1 << 24);
     T* carry = M.carry.template as<T>() + c0;
-    SpmmArgs<T> a{M.seg_start.template as<int64_t>(), M.seg_len.template as<int32_t>(), M.seg_info.template as<int32_t>(), M.n_seg,
+    SpmmArgs<T> a{M.seg_desc.template as<SegDesc>(), M.n_seg,
                   M.cols.template as<uint32_t>(), M.vals.template as<T>(), M.dest.template as<int32_t>(), M.n_dest,
                   B, ld, nc, out, carry, hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes,
                   M.tile_first.template as<int32_t>(), (int)M.n_tiles, M.tile_rows, M.tab_rows};
@@ -792,8 +797,12 @@ class Engine : public ImplBase {
       return 0;
     }
     const int nvec = ld / VEC;
-    const int vpl = nvec > 64 ? 2 : 1;
-    const int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
+    int vpl = nvec > 64 ? 2 : 1;
+    int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
+    // fp64 rows of 17..32 vectors (k = 33..64: 272..512 bytes): 16 lanes x 2 vectors per row instead of 32 x 1 -- four
+    // rows per wave-level gather as fp32 has, half the steps per nnz, and the 16-lane LDS paths (hot rows of H^T, W
+    // tiles) that never paid at 32 lanes (hot_x_threshold)
+    if (tune.two_vec && sizeof(T) == 8 && lpr == 32) lpr = 16, vpl = 2;
     const int ng = kWave / lpr;
     const int lds_ld = ld + lds_pad_for(ld, lpr);
     MNMF_TRY(ensure_prepared());
@@ -991,6 +1000,9 @@ class Engine : public ImplBase {
   }
 
   int spmm_dispatch(StreamMat<T>& M, const T* B, int ld, int nc, int c0, T* out, int hot, int lds_ld, int vpl, int lpr) {
+    if (vpl == 2 && lpr == 16) {
+      if constexpr (sizeof(T) == 8) return spmm_launch<16, 2>(M, B, ld, nc, c0, out, hot, lds_ld);
+    }
     if (vpl == 2) return spmm_launch<64, 2>(M, B, ld, nc, c0, out, hot, lds_ld);
     switch (lpr) {
       case 4: return spmm_launch<4, 1>(M, B, ld, nc, c0, out, hot, lds_ld);

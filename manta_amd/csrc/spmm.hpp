@@ -37,11 +37,19 @@
 
 namespace mnmf {
 
+// The kernels fetch (index, value) and destination lists a whole chunk at a time, without bounds tests: every stream
+// array (cols, vals, dest) is allocated with this many elements of slack behind its last entry.
+constexpr size_t kStreamPad = 512;
+
+struct alignas(16) SegDesc {
+  int64_t start;   // first nnz of the segment
+  int32_t len;     // nnz in the segment (0 = padding)
+  int32_t info;    // index into dest of the segment's first piece
+};
+
 template <typename T>
 struct SpmmArgs {
-  const int64_t* seg_start;  // [n_seg] first nnz of the segment
-  const int32_t* seg_len;    // [n_seg]
-  const int32_t* seg_info;   // [n_seg] index into dest of the segment's first piece
+  const SegDesc* seg;        // [n_seg]
   int64_t n_seg;
   const uint32_t* cols;      // gather index, top bit = end of piece
   const T* vals;
@@ -143,69 +151,120 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
     const int nvr = ld / VEC;
     const T* src = a.B + r0 * ld;
 #if MNMF_ABLATE != 5 && MNMF_ABLATE != 7   // 5, 7: timing experiment only, the tile is not staged
-    for (int i = threadIdx.x; i < nrow * nvr; i += blockDim.x) {
-      const int r = i / nvr, c = (i - r * nvr) * VEC;
-      *reinterpret_cast<VT*>(lds + (size_t)r * a.lds_ld + c) = *reinterpret_cast<const VT*>(src + (size_t)r * ld + c);
+    {
+      // the tile is contiguous in memory (nrow rows of ld elements); SU loads are in flight per thread before the first
+      // LDS write (one load at a time, each waited for, left a third of the tile's time to memory latency).  Buffer
+      // loads on a descriptor of the tile itself: past its end they return zeros, which are not stored.
+      constexpr int SU = 6;
+      const int total = nrow * nvr;
+      const bool same = a.lds_ld == ld;
+      __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src), 0, (uint32_t)total * 16u, 0x00020000);
+      for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * SU) {
+        U4 t[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(trs, (uint32_t)(i0 + u * (int)blockDim.x) * 16u, 0, 0);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = i0 + u * (int)blockDim.x;
+          if (i < total) {
+            uint32_t o = (uint32_t)i * 16u;
+            if (!same) {
+              const int r = i / nvr;
+              o = ((uint32_t)r * (uint32_t)a.lds_ld + (uint32_t)(i - r * nvr) * VEC) * (uint32_t)sizeof(T);
+            }
+            *reinterpret_cast<U4*>(reinterpret_cast<char*>(lds) + o) = t[u];
+          }
+        }
+      }
     }
 #endif
     __syncthreads();
     seg_lo = a.tile_first[tile];
     seg_hi = a.tile_first[tile + 1];
   }
-  const int64_t n_waves = (seg_hi - seg_lo + NG - 1) / NG;
-  const int64_t wave0 = TILE ? (int64_t)(threadIdx.x >> 6) : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t wave_stride = TILE ? (int64_t)(blockDim.x >> 6) : HOT ? ((int64_t)gridDim.x * blockDim.x) >> 6 : n_waves;
-  for (int64_t wave = wave0; wave < n_waves; wave += wave_stride) {
-    const int64_t seg = seg_lo + wave * NG + gi;
-    const uint32_t* cp = a.cols;
-    const T* vp = a.vals;
-    int rem = 0;  // nnz left in this group's segment
-    int j = 0;    // index of the current piece in dest[]
+  // Segment queue of this lane group.  PLAIN: one segment per group and launch (the grid covers the segments).
+  // HOT / TILE (persistent): group G of the NGT resident ones takes segments G, G + NGT, G + 2 NGT, ... of the tile
+  // (TILE) or of the whole stream (HOT) and walks them BACK TO BACK: the chunk prefetch of a segment's last chunk
+  // already fetches the first chunk of the group's next segment, whose descriptor was loaded two segments ahead.
+  // Before, a wave started its NG next segments together: descriptor load, then first chunk, two exposed trips to
+  // memory per ~100-500 nnz with 2-4 waves per SIMD to hide them (the waves of the tile kernel waited 58 % of their
+  // cycles, profiles/r02_bench_c2_mfma_lds_summary.json), plus the idle tail of every group but the wave's longest.
+  const int64_t gslot = TILE ? (int64_t)(threadIdx.x >> 6) : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t gstride = MODE == SPMM_PLAIN ? 0 : (TILE ? (int64_t)(blockDim.x >> 6) : ((int64_t)gridDim.x * blockDim.x) >> 6) * NG;
+  {
+    int64_t seg = seg_lo + gslot * NG + gi;
+    // descriptor of a segment (zero length past the end)
+    int64_t s0 = 0, s0n = 0, s0nn = 0;
+    int rem = 0, remn = 0, remnn = 0;   // nnz left in the current segment / length of the next two
+    int j = 0, jn = 0, jnn = 0;         // index of the current piece in dest[] / first piece of the next two
     if (seg < seg_hi) {
-      const int64_t s0 = a.seg_start[seg];
-      cp += s0;
-      vp += s0;
-      rem = a.seg_len[seg];
-      j = a.seg_info[seg];
+      const SegDesc d = a.seg[seg];
+      s0 = d.start, rem = d.len, j = d.info;
     }
+    if (MODE != SPMM_PLAIN) {
+      if (seg + gstride < seg_hi) {
+        const SegDesc d = a.seg[seg + gstride];
+        s0n = d.start, remn = d.len, jn = d.info;
+      }
+      if (seg + 2 * gstride < seg_hi) {
+        const SegDesc d = a.seg[seg + 2 * gstride];
+        s0nn = d.start, remnn = d.len, jnn = d.info;
+      }
+      seg += 2 * gstride;   // the segment whose descriptor was fetched last
+    }
+    const uint32_t* cp = a.cols + s0;
+    const T* vp = a.vals + s0;
     T acc[VPL][VEC];
 #pragma unroll
     for (int w = 0; w < VPL; ++w)
 #pragma unroll
       for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
     // chunk registers: lane li holds elements li*EPL + x of the chunk (col 0 / val 0 beyond the segment:
-    // such steps gather row 0, which is valid memory, and add 0)
+    // such steps gather row 0, which is valid memory, and add 0).  The loads have no bounds test (kStreamPad), so the
+    // EPL elements of a lane are one wide load; what lies beyond the segment is masked when the registers are taken over.
     uint32_t cl[EPL];
     T vl[EPL];
 #pragma unroll
     for (int x = 0; x < EPL; ++x) {
       const int q = li * EPL + x;
-      cl[x] = q < rem ? MNMF_NT_LOAD(cp + q) : 0u;
-      vl[x] = q < rem ? MNMF_NT_LOAD(vp + q) : T(0);
+      cl[x] = MNMF_NT_LOAD(cp + q);
+      vl[x] = MNMF_NT_LOAD(vp + q);
     }
-    // destinations of the next CH pieces of this group: lane li holds dest[j + x*LPR + li].  Like (index, value)
+    // destinations of the next CH pieces of this group: lane li holds dest[j + li*EPL + x].  Like (index, value)
     // they are fetched one chunk ahead: loaded at the start of the chunk that uses them, the first piece end of
     // every chunk waited for them with vmcnt(0) -- a full trip to memory, and in the PLAIN / HOT modes a drain of
     // every gather in flight.  Where the next chunk's list starts is known up front: j advances by the number of
     // end flags in the current chunk.
     int dl[EPL];
 #pragma unroll
-    for (int x = 0; x < EPL; ++x) {
-      const int64_t q = (int64_t)j + x * LPR + li;
-      dl[x] = (rem > 0 && q < a.n_dest) ? a.dest[q] : 0;
-    }
+    for (int x = 0; x < EPL; ++x) dl[x] = a.dest[(int64_t)j + li * EPL + x];
     // Retire the first chunk's loads before the loop: otherwise hipcc, merging "load still pending" from
     // the loop entry with the back edge, puts a vmcnt(0) inside the loop right behind the prefetch of the
     // next chunk and every chunk stalls for a full memory latency.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+      const bool in = li * EPL + x < rem;
+      cl[x] = in ? cl[x] : 0u;
+      vl[x] = in ? vl[x] : T(0);
+    }
     while (__any(rem > 0)) {
+      // what this group works on after the current chunk: the rest of its segment, or its next segment
+      const bool last = MODE != SPMM_PLAIN && rem <= CH;
+      // descriptor of the segment after the next two, fetched with every chunk (one 16-byte load per lane group, the
+      // first load of the iteration: behind a branch at the segment switch it would be waited for on the spot)
+      SegDesc dx = SegDesc{0, 0, 0};
+      if (MODE != SPMM_PLAIN) dx = a.seg[seg + gstride < seg_hi ? seg + gstride : seg_hi - 1];
+      const uint32_t* cq = last ? a.cols + s0n : cp + CH;
+      const T* vq = last ? a.vals + s0n : vp + CH;
+      const int remq = last ? remn : rem - CH;
       uint32_t cn[EPL];
       T vn[EPL];
 #pragma unroll
       for (int x = 0; x < EPL; ++x) {
-        const int q = CH + li * EPL + x;
-        cn[x] = q < rem ? MNMF_NT_LOAD(cp + q) : 0u;
-        vn[x] = q < rem ? MNMF_NT_LOAD(vp + q) : T(0);
+        const int q = li * EPL + x;
+        cn[x] = MNMF_NT_LOAD(cq + q);
+        vn[x] = MNMF_NT_LOAD(vq + q);
       }
       const int jbase = j;
       // end-of-piece flags of the whole chunk as wave-level bit masks (bit = holder lane): the per-step
@@ -224,11 +283,9 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
           const uint64_t mine = LPR == 64 ? em[x] : (em[x] >> gbase) & (((uint64_t)1 << (LPR & 63)) - 1);
           ends += __popcll(mine);
         }
+        const int64_t jq = last ? (int64_t)jn : (int64_t)j + ends;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) {
-          const int64_t q = (int64_t)j + ends + x * LPR + li;
-          dn[x] = (rem > CH && q < a.n_dest) ? a.dest[q] : 0;
-        }
+        for (int x = 0; x < EPL; ++x) dn[x] = a.dest[jq + li * EPL + x];
       }
       static_for<CH / U>([&](auto ib) {
         constexpr int u0 = decltype(ib)::value * U;
@@ -310,12 +367,12 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
             int d = 0;
             uint64_t pend = eb & gmask;
             if (!TILE) {  // vector-memory gathers: nothing of theirs waits behind a ds_bpermute
-              const int idx = j - jbase;
-              d = shfl_i(dl[0], gbase + (idx % LPR));
+              const int idx = j - jbase;   // entry idx of the group's list: register idx % EPL of lane idx / EPL
+              d = shfl_i(dl[0], gbase + (idx / EPL));
 #pragma unroll
               for (int x = 1; x < EPL; ++x) {
-                const int dx = shfl_i(dl[x], gbase + (idx % LPR));
-                d = (idx / LPR == x) ? dx : d;
+                const int dx = shfl_i(dl[x], gbase + (idx / EPL));
+                d = (idx % EPL == x) ? dx : d;
               }
               pend = 0;
             }
@@ -323,11 +380,11 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
               const int b = __builtin_ctzll(pend);  // first lane of the group
               pend &= pend - 1;
               const int idx = __builtin_amdgcn_readlane(j - jbase, b);  // < CH, uniform inside the group
-              int dg = __builtin_amdgcn_readlane(dl[0], b + (idx % LPR));
+              int dg = __builtin_amdgcn_readlane(dl[0], b + (idx / EPL));
 #pragma unroll
               for (int x = 1; x < EPL; ++x) {
-                const int dx = __builtin_amdgcn_readlane(dl[x], b + (idx % LPR));
-                dg = (idx / LPR == x) ? dx : dg;
+                const int dx = __builtin_amdgcn_readlane(dl[x], b + (idx / EPL));
+                dg = (idx % EPL == x) ? dx : dg;
               }
               d = gbase == b ? dg : d;
             }
@@ -354,13 +411,25 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
           }
         }
       });
-      rem -= CH;
-      cp += CH;
-      vp += CH;
+      if (last) {   // on to the group's next segment; the descriptor after it is fetched behind this chunk's prefetch
+        j = jn;
+        s0n = s0nn;
+        remn = remnn;
+        jn = jnn;
+        seg += gstride;
+        const bool more = seg < seg_hi;
+        s0nn = more ? dx.start : 0;
+        remnn = more ? dx.len : 0;
+        jnn = more ? dx.info : 0;
+      }
+      rem = remq;
+      cp = cq;
+      vp = vq;
 #pragma unroll
       for (int x = 0; x < EPL; ++x) {
-        cl[x] = cn[x];
-        vl[x] = vn[x];
+        const bool in = li * EPL + x < rem;   // beyond the segment: index 0, value 0
+        cl[x] = in ? cn[x] : 0u;
+        vl[x] = in ? vn[x] : T(0);
         dl[x] = dn[x];
       }
     }
