@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -84,16 +85,20 @@ struct Tune {
   int64_t hot_x_min_nnz = -1;         // X.H^T: smallest matrix that takes the LDS-hot kernel; -1 = the measured rule (hot_x_threshold)
   int64_t xt_long_floor = 128;        // X^T blocked stream: words with at most this many nnz are never cut at document blocks
   int lds_pad = -1;                   // padding of a factor row in the LDS images (elements); < 0: lds_pad_for()
-  int sweep = 0;                      // X^T.W: rare words through the synchronised sweep (0 off: measured 1.6 % slower at C2; 1 when the shape suits it; 2 always: tests)
+  int sweep = 1;                      // X^T.W: rare words through the synchronised sweep (0 off; 1 when the shape suits it; 2 always: tests)
   int64_t sweep_lds_bytes = 150 << 10; // LDS for the accumulator rows of one partition
-  int64_t sweep_win_bytes = 2 << 20;  // bytes of W rows per document window (two windows should fit an XCD's L2)
+  int64_t sweep_win_bytes = 8 << 20;  // bytes of W rows per document window (configs[1], sweep kernel alone for df <= 244: 1 / 2 / 4 / 8 / 16 / 64 MiB 544 / 333 / 304 / 246 / 260 / 305 us: fewer barriers against reuse in L2)
   int sweep_min_touch_pct = 100;      // use it only if a document is gathered at least this often (percent) per XCD: below, no reuse
-  int64_t sweep_max_df = 0;           // words with up to this many nnz (at least the uncut ones) go to the sweep
+  int64_t sweep_max_df = 0;           // words with up to this many nnz (at least the uncut ones) go to the sweep; 0 = 32 per window
+  int64_t sweep_min_table_bytes = 64 << 20;  // ... and only if the gathered table is at least this large
   int sweep_order = 1;                // 0: sweep first, beside the blocked stream; 1: tile || blocked, then the sweep alone; 2: blocked || tile after, sweep last
   int rk_one_pass = 0;                // (measured 4 % slower at the configs[4] shard: the kernel is matrix-core bound) fp32 update with 128 < k <= 256: all column tiles of a row tile in one wave
   int mfma_f64 = 1;                   // fp64 update + fused Grams on the matrix cores (k <= 64)
   int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
+  int exact_seg = 0;                  // segments of exactly q nnz (pieces cut at the boundary): 1 X^T blocked stream, 2 every stream
+  int queue = 0;                      // X^T blocked stream as a persistent launch with per-lane-group segment queues (2: the plain X stream too)
+  int queue_wgs = 0;                  // ... workgroups per CU; 0 = what the occupancy calculator says
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
@@ -132,6 +137,9 @@ struct Tune {
     xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
+    queue = (int)geti("MNMF_QUEUE", queue);
+    exact_seg = (int)geti("MNMF_EXACT_SEG", exact_seg);
+    queue_wgs = (int)geti("MNMF_QUEUE_WGS", queue_wgs);
     rs_ag = (int)geti("MNMF_RS_AG", rs_ag);
     mfma_f64 = (int)geti("MNMF_MFMA_F64", mfma_f64);
     rk_one_pass = (int)geti("MNMF_RK_ONE_PASS", rk_one_pass);
@@ -140,6 +148,7 @@ struct Tune {
     sweep_max_df = geti("MNMF_SWEEP_MAX_DF", sweep_max_df);
     sweep_lds_bytes = geti("MNMF_SWEEP_LDS_BYTES", sweep_lds_bytes);
     sweep_win_bytes = geti("MNMF_SWEEP_WIN_BYTES", sweep_win_bytes);
+    sweep_min_table_bytes = geti("MNMF_SWEEP_MIN_TABLE_BYTES", sweep_min_table_bytes);
     sweep_min_touch_pct = (int)geti("MNMF_SWEEP_MIN_TOUCH_PCT", sweep_min_touch_pct);
   }
 };
@@ -235,6 +244,7 @@ class Engine : public ImplBase {
   DevBuf d_newid, d_order;   // int32 newid[old], uint32 order[new]
   const int32_t* vmap() const { return (prepared && renumbered) ? d_newid.template as<int32_t>() : nullptr; }
   int n_cus = 256;
+  std::unordered_map<const void*, int> occ_cache;   // resident 256-thread workgroups per CU of the persistent SpMM kernels
   // solver workspaces
   DevBuf Wb[2], Hb[2], Nw, Ex, Aux1, Aux2, slab, small, tmpA, tmpB, tmpC, tmpD, ar_pack;
   double* h_pinned = nullptr;
@@ -499,33 +509,49 @@ class Engine : public ImplBase {
       E_HIP(rare.ensure((size_t)V * 4));
       E_HIP(rare_df.ensure((size_t)V * 4));
       E_HIP(rare_idx.ensure((size_t)V * 4));
-      const int32_t sweep_df = (int32_t)std::min<int64_t>(std::max<int64_t>(long_df, tune.sweep_max_df), 1 << 30);
-      rare_mark_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(df.template as<int32_t>(), V, (uint32_t)n_hot, sweep_df,
-                                                               rare.template as<int32_t>(), rare_df.template as<int32_t>());
-      E_LAUNCH();
-      int32_t h2[2] = {0, 0};
-      for (int which = 0; which < 2; ++which) {   // number of rare words, and their nnz
-        const int32_t* src = which == 0 ? rare.template as<int32_t>() : rare_df.template as<int32_t>();
-        size_t bytes = 0;
-        E_HIP(rocprim::reduce(nullptr, bytes, src, cnt.template as<int32_t>(), 0, (size_t)V, rocprim::plus<int32_t>(), st()));
-        E_HIP(tmp.ensure(bytes));
-        E_HIP(rocprim::reduce(tmp.p, bytes, src, cnt.template as<int32_t>(), 0, (size_t)V, rocprim::plus<int32_t>(), st()));
-        E_HIP(hipMemcpyAsync(&h2[which], cnt.p, 4, hipMemcpyDeviceToHost, st()));
-        E_HIP(hipStreamSynchronize(st()));
-      }
-      const int64_t n_rare = h2[0], rare_nnz = h2[1];
-      const int P = n_cus;
-      const int64_t rpp = std::max<int64_t>(1, cdiv(n_rare, P));
       int ws = 8;   // window: about sweep_win_bytes of table rows (ld * sizeof(T) bytes each = sweep_row_bytes less the padding)
       while (ws < 24 && ((int64_t)2 << ws) * (int64_t)sweep_row_bytes <= tune.sweep_win_bytes) ++ws;
       const int64_t n_win = cdiv(m, (int64_t)1 << ws);
+      // which words: the uncut ones, and up to about 32 nnz per window (one lane group accumulates a word's nnz of a
+      // window one after the other; beyond that the heaviest word holds its window back: configs[1], 32 windows,
+      // X^T.W with df <= 700 / 1000 / 1500 / 2000 / 4000: 1.197 / 1.196 / 1.227 / 1.259 / 1.397 ms)
+      const int64_t auto_df = tune.sweep_max_df > 0 ? tune.sweep_max_df : 32 * n_win;
+      const int32_t sweep_df = (int32_t)std::min<int64_t>(std::max<int64_t>(long_df, auto_df), 1 << 30);
+      // The accumulator rows of all partitions hold `cap` words.  When more words qualify (wide rows: few rows per
+      // partition; large vocabularies), the rarest ones stay in the blocked stream: words with lo < df <= sweep_df go to
+      // the sweep, lo doubled until they fit -- a word with a handful of nnz brings the least work per accumulator row.
+      const int P = n_cus;
+      const int64_t cap = (int64_t)P * (int64_t)(tune.sweep_lds_bytes / (int64_t)sweep_row_bytes);
+      int32_t h2[2] = {0, 0};
+      int32_t sweep_lo = 0;
+      for (;;) {
+        rare_mark_kernel<<<(unsigned)cdiv(V, TB), TB, 0, st()>>>(df.template as<int32_t>(), V, (uint32_t)n_hot, sweep_lo, sweep_df,
+                                                                 rare.template as<int32_t>(), rare_df.template as<int32_t>());
+        E_LAUNCH();
+        for (int which = 0; which < 2; ++which) {   // number of rare words, and their nnz
+          const int32_t* src = which == 0 ? rare.template as<int32_t>() : rare_df.template as<int32_t>();
+          size_t bytes = 0;
+          E_HIP(rocprim::reduce(nullptr, bytes, src, cnt.template as<int32_t>(), 0, (size_t)V, rocprim::plus<int32_t>(), st()));
+          E_HIP(tmp.ensure(bytes));
+          E_HIP(rocprim::reduce(tmp.p, bytes, src, cnt.template as<int32_t>(), 0, (size_t)V, rocprim::plus<int32_t>(), st()));
+          E_HIP(hipMemcpyAsync(&h2[which], cnt.p, 4, hipMemcpyDeviceToHost, st()));
+          E_HIP(hipStreamSynchronize(st()));
+        }
+        if (h2[0] <= cap || cap <= 0 || sweep_lo >= sweep_df) break;
+        sweep_lo = sweep_lo > 0 ? sweep_lo * 2 : 1;
+      }
+      const int64_t n_rare = h2[0], rare_nnz = h2[1];
+      const int64_t rpp = std::max<int64_t>(1, cdiv(n_rare, P));
       const uint64_t sbase = (uint64_t)hot_span + (uint64_t)(n_blocks + 1) * (uint64_t)V;
       const bool fits = n_rare > 0 && (uint64_t)rpp * sweep_row_bytes <= (uint64_t)tune.sweep_lds_bytes &&
                         sbase + (uint64_t)n_win * P * (uint64_t)rpp < ((uint64_t)1 << 32) && rare_nnz < ((int64_t)1 << 31) &&
                         m < ((int64_t)1 << 24) && (uint64_t)m * sweep_row_bytes < ((uint64_t)1 << 32) &&
                         n_win * P * 64 < ((int64_t)1 << 30);
       // a document's row is fetched from the fabric once per XCD and sweep; it pays when the XCD then uses it again
-      const bool pays = rare_nnz * 100 >= (int64_t)tune.sweep_min_touch_pct * 8 * m && nnz >= tune.hot_min_nnz;
+      // ... and when the table is beyond what the L2s hold together (configs[0], 2.5 MB of W: X^T.W 0.055 -> 0.093 ms with
+      // the sweep; there every gather of the blocked stream is an L2 hit anyway)
+      const bool pays = rare_nnz * 100 >= (int64_t)tune.sweep_min_touch_pct * 8 * m && nnz >= tune.hot_min_nnz &&
+                        (int64_t)m * (int64_t)sweep_row_bytes >= tune.sweep_min_table_bytes;
       if (fits && (pays || tune.sweep >= 2)) {
         size_t bytes = 0;
         E_HIP(rocprim::exclusive_scan(nullptr, bytes, rare.template as<int32_t>(), rare_idx.template as<int32_t>(), 0, (size_t)V,
@@ -664,7 +690,8 @@ class Engine : public ImplBase {
     std::vector<int32_t> tile_first;
     const bool tiled = M.tile_rows > 0;
     if (tiled && q <= 0) build_tile_segments_host(M.pieces, M.rows, M.n_tiles, (int)(-q), kSubPiece, s, tile_first);  // -q = groups
-    else build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group, tiled ? &tile_first : nullptr, M.n_tiles);
+    else build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group, tiled ? &tile_first : nullptr, M.n_tiles,
+                             tune.exact_seg > 0 && (&M == &Xt || tune.exact_seg >= 2));
     if (tiled) MNMF_TRY(upload(M.tile_first, tile_first.data(), tile_first.size() * 4));
     M.seg_group = xcd_group;
     M.n_seg = s.n_seg();
@@ -743,6 +770,25 @@ class Engine : public ImplBase {
       E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       kern<<<(unsigned)n_cus, 1024, lds_bytes, st()>>>(a);
       E_LAUNCH();
+    } else if (waves > 0 && !wide && tune.queue && (&M == &Xt || tune.queue >= 2)) {
+      // persistent PLAIN: lane groups walk their segment queues back to back (spmm.hpp, SPMM_QUEUE).  The grid is what
+      // is resident at once, a multiple of 8 workgroups so that workgroup w still runs the segments meant for XCD w % 8.
+      a.hot_rows = 0;
+      auto launch_queue = [&](auto kern) -> int {
+        int& occ = occ_cache[reinterpret_cast<const void*>(kern)];
+        if (occ == 0) {
+          int o = 0;
+          E_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, 256, 0));
+          occ = std::max(1, o);
+        }
+        const int per_cu = tune.queue_wgs > 0 ? tune.queue_wgs : occ;
+        const unsigned grid = (unsigned)std::min<int64_t>(round_up(cdiv(waves, 4), 8), (int64_t)n_cus * per_cu);
+        kern<<<grid, 256, 0, st()>>>(a);
+        E_LAUNCH();
+        return 0;
+      };
+      if (&M == &Xt) MNMF_TRY(launch_queue(spmm_stream_kernel<T, LPR, VPL, 1, SPMM_QUEUE, false>));
+      else MNMF_TRY(launch_queue(spmm_stream_kernel<T, LPR, VPL, 0, SPMM_QUEUE, false>));
     } else if (waves > 0) {
       a.hot_rows = 0;
       const unsigned grid = (unsigned)cdiv(waves, 4);
@@ -831,7 +877,7 @@ class Engine : public ImplBase {
         if (tile_rows < min_rows || n_hot < 8 || cdiv(m, tile_rows) < std::max<int64_t>(min_tiles, 4)) n_hot = 0;
       }
       // rare words: synchronised sweep with LDS accumulators (one vector per lane only)
-      const size_t sweep_rb = (vmap() && tune.sweep > 0 && vpl == 1 && !tune.force_wide) ? (size_t)lds_ld * sizeof(T) : 0;
+      const size_t sweep_rb = (vmap() && tune.sweep > 0 && (vpl == 1 || lpr == 16) && !tune.force_wide) ? (size_t)lds_ld * sizeof(T) : 0;
       MNMF_TRY(ensure_xt(bs, n_hot, tile_rows, sweep_rb));
     }
     if (&M == &Xt && Xs.nnz > 0) {
@@ -847,7 +893,7 @@ class Engine : public ImplBase {
         E_HIP(hipEventRecord(ev_fork, ctx->stream));
         E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
       }
-      if (tune.sweep_order == 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr));
+      if (tune.sweep_order == 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
       if (tune.sweep_order == 1 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       if (Xt.nnz > 0) {
         if (fork) st_override = side_stream;
@@ -860,7 +906,7 @@ class Engine : public ImplBase {
         E_HIP(hipEventRecord(ev_join, side_stream));
         E_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
       }
-      if (tune.sweep_order != 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr));
+      if (tune.sweep_order != 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
       return 0;
     }
     if (&M == &Xt && Xth.nnz > 0 && tune.xt_overlap) {
@@ -968,7 +1014,7 @@ class Engine : public ImplBase {
     return spmm_dispatch(M, B, ld, ld, 0, out, hot, lds_ld, vpl, lpr);
   }
 
-  template <int LPR>
+  template <int LPR, int VPL = 1>
   int sweep_launch(const T* B, int ld, T* out, int lds_ld) {
     constexpr int NGW = 16 * (kWave / LPR);
     const int64_t n_cells = (int64_t)Xs.n_windows * Xs.P;
@@ -982,14 +1028,18 @@ class Engine : public ImplBase {
     SweepArgs<T> a{Xs.seg.template as<int32_t>(), Xs.n_windows, Xs.docs.template as<uint32_t>(), Xs.lrows.template as<uint32_t>(),
                    Xs.vals.template as<T>(), B, ld, lds_ld, Xs.rpp, (uint32_t)((size_t)m * ld * sizeof(T)),
                    Xs.words.template as<int32_t>(), out};
-    auto kern = spmm_sweep_kernel<T, LPR, 1>;
+    auto kern = spmm_sweep_kernel<T, LPR, VPL>;
     const size_t lds_bytes = (size_t)Xs.rpp * lds_ld * sizeof(T) + 64;
     E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     kern<<<(unsigned)Xs.P, 1024, lds_bytes, st()>>>(a);
     E_LAUNCH();
     return 0;
   }
-  int sweep_dispatch(const T* B, int ld, T* out, int lds_ld, int lpr) {
+  int sweep_dispatch(const T* B, int ld, T* out, int lds_ld, int lpr, int vpl = 1) {
+    if (vpl == 2) {
+      if constexpr (sizeof(T) == 8) return sweep_launch<16, 2>(B, ld, out, lds_ld);
+      return fail(MNMF_ESTATE, "sweep: two vectors per lane only for 16-lane fp64 rows");
+    }
     switch (lpr) {
       case 4: return sweep_launch<4>(B, ld, out, lds_ld);
       case 8: return sweep_launch<8>(B, ld, out, lds_ld);

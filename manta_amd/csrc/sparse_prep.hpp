@@ -114,15 +114,52 @@ inline void build_tile_segments_host(const HostPieces& pc, int64_t rows, int64_t
 // tile_first != nullptr (tile stream, the default mode): segments of about seg_nnz nnz that are closed at tile
 // boundaries and stay in stream order; tile_first[t] = first segment of tile t; no empty-row list.
 inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_nnz, int64_t sub, HostSegments& s,
-                                int xcd_group = 0, std::vector<int32_t>* tile_first = nullptr, int64_t n_tiles = 0) {
+                                int xcd_group = 0, std::vector<int32_t>* tile_first = nullptr, int64_t n_tiles = 0,
+                                bool exact = false) {
+  // exact: a segment is closed after exactly seg_nnz nnz (the piece is cut there and both parts get carry slots), so
+  // the lane groups of a wave, which work on consecutive segments, finish together; otherwise a segment ends with the
+  // (sub-)piece that takes it to seg_nnz or beyond, and is up to `sub` nnz longer.
   s = HostSegments();
   if (seg_nnz < 1) seg_nnz = 1;
   if (sub < 1) sub = 1;
   const int64_t np = (int64_t)pc.row.size();
   const bool tiled = tile_first != nullptr && pc.block.size() == pc.row.size();
   const bool blocked = (xcd_group > 0 || tiled) && pc.block.size() == pc.row.size();
+  // pass 1: parts (sub-pieces) and segments in processing order
+  struct Part { int64_t b; int32_t row; };
+  std::vector<Part> parts;
   std::vector<int32_t> cnt((size_t)rows, 0);
-  for (int64_t p = 0; p < np; ++p) cnt[pc.row[p]] += (int32_t)cdiv(pc.start[p + 1] - pc.start[p], sub);
+  std::vector<int32_t> seg_block;
+  int64_t cur = -1;
+  int32_t cur_block = 0;
+  for (int64_t p = 0; p < np; ++p) {
+    const int32_t r = pc.row[p];
+    const int32_t blk = blocked ? pc.block[p] : 0;
+    if (blocked && cur >= 0 && blk != cur_block) {  // close the open segment at a block boundary
+      s.seg_len.push_back((int32_t)(pc.start[p] - cur));
+      cur = -1;
+    }
+    for (int64_t a = pc.start[p]; a < pc.start[p + 1];) {
+      if (cur < 0) {
+        cur = a;
+        cur_block = blk;
+        s.seg_start.push_back(a);
+        s.seg_info.push_back((int32_t)parts.size());
+        seg_block.push_back(blk);
+      }
+      int64_t b = std::min(a + sub, pc.start[p + 1]);
+      if (exact) b = std::min(b, cur + seg_nnz);
+      parts.push_back({b, r});
+      ++cnt[r];
+      if (b - cur >= seg_nnz) {
+        s.seg_len.push_back((int32_t)(b - cur));
+        cur = -1;
+      }
+      a = b;
+    }
+  }
+  if (cur >= 0) s.seg_len.push_back((int32_t)(pc.start[np] - cur));
+  // pass 2: carry table and destinations
   std::vector<int32_t> first((size_t)rows, 0);
   for (int64_t r = 0; r < rows; ++r) {
     if (cnt[r] == 0 && !tiled) s.empty_rows.push_back((int32_t)r);
@@ -135,34 +172,12 @@ inline void build_segments_host(const HostPieces& pc, int64_t rows, int64_t seg_
     }
   }
   std::vector<int32_t> used((size_t)rows, 0);
-  std::vector<int32_t> seg_block;
-  int64_t cur = -1;
-  int32_t cur_block = 0;
-  for (int64_t p = 0; p < np; ++p) {
-    const int32_t r = pc.row[p];
-    const int32_t blk = blocked ? pc.block[p] : 0;
-    if (blocked && cur >= 0 && blk != cur_block) {  // close the open segment at a block boundary
-      s.seg_len.push_back((int32_t)(pc.start[p] - cur));
-      cur = -1;
-    }
-    for (int64_t a = pc.start[p]; a < pc.start[p + 1]; a += sub) {
-      const int64_t b = std::min(a + sub, pc.start[p + 1]);
-      if (cur < 0) {
-        cur = a;
-        cur_block = blk;
-        s.seg_start.push_back(a);
-        s.seg_info.push_back((int32_t)s.dest.size());
-        seg_block.push_back(blk);
-      }
-      s.dest.push_back(cnt[r] > 1 ? ~(first[r] + used[r]++) : r);
-      s.piece_end.push_back(b - 1);
-      if (b - cur >= seg_nnz) {
-        s.seg_len.push_back((int32_t)(b - cur));
-        cur = -1;
-      }
-    }
+  s.dest.reserve(parts.size());
+  s.piece_end.reserve(parts.size());
+  for (const Part& pt : parts) {
+    s.dest.push_back(cnt[pt.row] > 1 ? ~(first[pt.row] + used[pt.row]++) : pt.row);
+    s.piece_end.push_back(pt.b - 1);
   }
-  if (cur >= 0) s.seg_len.push_back((int32_t)(pc.start[np] - cur));
   if (tiled) {
     tile_first->assign((size_t)n_tiles + 1, 0);
     const int64_t ns = s.n_seg();
@@ -285,12 +300,12 @@ static __global__ void transpose_key_kernel(const uint32_t* __restrict__ cols, c
   key[p] = hot_span + (uint32_t)((uint64_t)b * (uint64_t)V + c);
 }
 
-// rare[c] = 1 for the words of the sweep stream: not in the tile stream, at most long_df nnz, at least one
-static __global__ void rare_mark_kernel(const int32_t* __restrict__ df, int64_t V, uint32_t n_hot, int32_t long_df,
+// rare[c] = 1 for the words of the sweep stream: not in the tile stream, more than lo_df (>= 0) and at most long_df nnz
+static __global__ void rare_mark_kernel(const int32_t* __restrict__ df, int64_t V, uint32_t n_hot, int32_t lo_df, int32_t long_df,
                                         int32_t* __restrict__ rare, int32_t* __restrict__ rare_df) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= V) return;
-  const int r = (c >= n_hot && df[c] > 0 && df[c] <= long_df) ? 1 : 0;
+  const int r = (c >= n_hot && df[c] > lo_df && df[c] <= long_df) ? 1 : 0;
   rare[c] = r;
   rare_df[c] = r ? df[c] : 0;
 }

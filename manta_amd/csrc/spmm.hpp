@@ -25,6 +25,9 @@
 #define MNMF_NT_LOAD(p) (*(p))
 #endif
 
+#ifndef MNMF_NT_STORE
+#define MNMF_NT_STORE 0
+#endif
 #ifndef MNMF_TILE_CH
 #define MNMF_TILE_CH 32   // nnz per stream chunk in the TILE mode (prefetch distance)
 #endif
@@ -70,7 +73,12 @@ struct SpmmArgs {
   int64_t tab_rows;          // rows of B
 };
 
-enum SpmmMode { SPMM_PLAIN = 0, SPMM_HOT = 1, SPMM_TILE = 2 };
+// SPMM_QUEUE: the PLAIN kernel as a persistent launch (a few 256-thread workgroups per CU): like HOT without the LDS
+// image, every lane group walks its own queue of segments back to back.  The four groups of a wave no longer wait for
+// the longest of their four segments (X^T blocked stream of the mid-frequency words: pieces of up to 512 nnz make
+// segments of 128..600 nnz, and 43 % of the wave-level gathers were issued for groups that had finished,
+// TA_BUFFER_READ_WAVEFRONTS against nnz / 4), and the number of segments in flight is what fits the CUs.
+enum SpmmMode { SPMM_PLAIN = 0, SPMM_HOT = 1, SPMM_TILE = 2, SPMM_QUEUE = 3 };
 
 // The inner loop is written for a low instruction count per nnz (the gather of 16 B per lane is the
 // only memory instruction per step): 32-bit offsets, one v_mad_u32_u24 per gather address (it ignores
@@ -90,7 +98,7 @@ enum SpmmMode { SPMM_PLAIN = 0, SPMM_HOT = 1, SPMM_TILE = 2 };
 // the nnz stream and the carry stores.  Profiling showed both SpMMs bound by the texture-addresser (TA busy
 // 80-93 %), which this takes out of the picture for about half of the nnz.
 template <typename T, int LPR, int VPL, int DIR, int MODE, bool WIDE>
-__global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
+__global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
   constexpr bool HOT = MODE == SPMM_HOT;
   constexpr bool TILE = MODE == SPMM_TILE;
   constexpr int VEC = VecOf<T>::N;
@@ -401,7 +409,13 @@ __global__ __launch_bounds__(MODE != SPMM_PLAIN ? 1024 : 256) void spmm_stream_k
                   VT o;
 #pragma unroll
                   for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
+#if MNMF_NT_STORE   // experiment: output rows and carries are written once and read by another kernel
+                  U4 ou;
+                  __builtin_memcpy(&ou, &o, sizeof(VT));
+                  __builtin_nontemporal_store(ou, reinterpret_cast<U4*>(reinterpret_cast<char*>(op) + cbytes[w]));
+#else
                   *reinterpret_cast<VT*>(reinterpret_cast<char*>(op) + cbytes[w]) = o;
+#endif
                 }
 #pragma unroll
                 for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);

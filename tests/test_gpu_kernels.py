@@ -282,3 +282,26 @@ def test_spmm_transposed_through_the_sweep_stream(dtype, k, monkeypatch):
             assert rel(host(H), want["H"]) <= (1e-10 if dtype == "fp64" else 1e-4)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("dtype,k", [("fp32", 20), ("fp64", 50)])
+def test_sweep_keeps_the_rarest_words_out_when_the_accumulators_do_not_fit(dtype, k, monkeypatch):
+    """More qualifying words than accumulator rows (a tiny LDS budget here; wide rows or large vocabularies in
+    practice): the rarest words stay in the blocked stream (the lower df bound is doubled until the rest fits) and the
+    product is still scipy's, bit-identical run to run."""
+    from manta_amd.engine import Engine
+
+    monkeypatch.setenv("MNMF_SWEEP", "2")
+    monkeypatch.setenv("MNMF_SWEEP_WIN_BYTES", "32768")
+    monkeypatch.setenv("MNMF_SWEEP_LDS_BYTES", "1024")     # 2-8 rows per partition: about 500-2000 of the 2500 words
+    X = make_x(3000, 2500, seed=7 + k)
+    eng = Engine(dtype=dtype)
+    try:
+        eng.set_matrix(X)
+        A = np.random.RandomState(k).rand(3000, k)
+        got = host(eng.spmm(A, transpose=True))
+        assert rel(got, X.T @ A) <= TOL[dtype]
+        assert np.all(got[np.diff(X.tocsc().indptr) == 0] == 0)
+        assert np.array_equal(got, host(eng.spmm(A, transpose=True)))
+    finally:
+        eng.close()
