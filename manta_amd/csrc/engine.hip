@@ -96,7 +96,7 @@ struct Tune {
   int mfma_f64 = 1;                   // fp64 update + fused Grams on the matrix cores (k <= 64)
   int rs_ag = 1;                      // sharded NMF / NMTF: reduce-scatter -> slice update -> all-gather (needs mnmf_set_comm)
   int force_wide = 0;                 // tests: take the 64-bit-address SpMM variant whatever the table size
-  int exact_seg = 0;                  // segments of exactly q nnz (pieces cut at the boundary): 1 X^T blocked stream, 2 every stream
+  int exact_seg = -1;                 // segments of exactly q nnz (pieces cut at the boundary): -1 by size (ensure_segments), 0 never, 1 X^T blocked stream, 2 every stream
   int queue = 0;                      // X^T blocked stream as a persistent launch with per-lane-group segment queues (2: the plain X stream too)
   int queue_wgs = 0;                  // ... workgroups per CU; 0 = what the occupancy calculator says
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
@@ -684,14 +684,24 @@ class Engine : public ImplBase {
     return 0;
   }
 
-  int ensure_segments(StreamMat<T>& M, int64_t q, int xcd_group) {
+  int ensure_segments(StreamMat<T>& M, int64_t q, int xcd_group, int ng) {
     if (M.seg_q == q && M.seg_group == xcd_group && M.flags_set) return 0;
     HostSegments s;
     std::vector<int32_t> tile_first;
     const bool tiled = M.tile_rows > 0;
     if (tiled && q <= 0) build_tile_segments_host(M.pieces, M.rows, M.n_tiles, (int)(-q), kSubPiece, s, tile_first);  // -q = groups
-    else build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group, tiled ? &tile_first : nullptr, M.n_tiles,
-                             tune.exact_seg > 0 && (&M == &Xt || tune.exact_seg >= 2));
+    else {
+      // Exact-length segments (pieces cut at the segment boundary) for small streams: the whole stream is then about one
+      // round of the resident waves, the kernel lasts as long as its slowest wave, and a wave as long as the longest of
+      // its segments (configs[0], 1.8e6 nnz: X^T.W 0.054 -> 0.036 ms, X.H^T 0.033 -> 0.028 ms, 8740 -> 10870 it/s; 30k
+      // documents: X^T.W 0.055 -> 0.044; 50k: X^T.W 0.060 -> 0.057 but X.H^T 0.048 -> 0.053).  With more rounds the
+      // dispatcher evens the waves out and the extra carry slots of the cut pieces cost more than they save (100k x
+      // 50k, k = 20: X^T.W 0.096 -> 0.113 ms; configs[1]: 1.355 -> 1.404 ms).
+      (void)ng;
+      const bool few_waves = M.nnz <= (&M == &Xt ? (int64_t)5000000 : (int64_t)2200000);
+      const bool exact = tune.exact_seg < 0 ? (few_waves && !tiled) : (tune.exact_seg > 0 && (&M == &Xt || tune.exact_seg >= 2));
+      build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group, tiled ? &tile_first : nullptr, M.n_tiles, exact);
+    }
     if (tiled) MNMF_TRY(upload(M.tile_first, tile_first.data(), tile_first.size() * 4));
     M.seg_group = xcd_group;
     M.n_seg = s.n_seg();
@@ -995,7 +1005,7 @@ class Engine : public ImplBase {
     const int xcd_group = (&M == &Xt && tune.xcd_affinity && Xt.pieces.block.size() == Xt.pieces.row.size() &&
                            !Xt.pieces.row.empty()) ? 4 * ng : 0;
     if (part != 2) {
-      MNMF_TRY(ensure_segments(M, q, xcd_group));
+      MNMF_TRY(ensure_segments(M, q, xcd_group, ng));
       if (M.n_carry > 0) E_HIP(M.carry.ensure((size_t)M.n_carry * ld * sizeof(T)));
       if (M.n_empty > 0) {
         zero_rows_kernel<T><<<(unsigned)cdiv(M.n_empty * ld, 256), 256, 0, st()>>>(M.empty_rows.template as<int32_t>(), M.n_empty,
