@@ -698,7 +698,7 @@ class Engine : public ImplBase {
       // dispatcher evens the waves out and the extra carry slots of the cut pieces cost more than they save (100k x
       // 50k, k = 20: X^T.W 0.096 -> 0.113 ms; configs[1]: 1.355 -> 1.404 ms).
       (void)ng;
-      const bool few_waves = M.nnz <= (&M == &Xt ? (int64_t)5000000 : (int64_t)2200000);
+      const bool few_waves = nnz <= (&M == &Xt ? (int64_t)5000000 : (int64_t)2200000);   // the whole matrix, not this stream's share
       const bool exact = tune.exact_seg < 0 ? (few_waves && !tiled) : (tune.exact_seg > 0 && (&M == &Xt || tune.exact_seg >= 2));
       build_segments_host(M.pieces, M.rows, q, kSubPiece, s, xcd_group, tiled ? &tile_first : nullptr, M.n_tiles, exact);
     }
@@ -904,19 +904,22 @@ class Engine : public ImplBase {
         E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
       }
       if (tune.sweep_order == 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
-      if (tune.sweep_order == 1 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      if ((tune.sweep_order == 1 || tune.sweep_order == 3) && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       if (Xt.nnz > 0) {
         if (fork) st_override = side_stream;
         const int r = spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2);
         st_override = nullptr;
         MNMF_TRY(r);
       }
-      if (tune.sweep_order != 1 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      if (tune.sweep_order != 1 && tune.sweep_order != 3 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      // order 3: the sweep follows the tile stream on the caller's stream, before the join -- its workgroups take the CUs
+      // as the tile kernel's drain, beside the tail of the blocked stream and the fix-up kernels of both streams
+      if (tune.sweep_order == 3) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
       if (fork) {
         E_HIP(hipEventRecord(ev_join, side_stream));
         E_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
       }
-      if (tune.sweep_order != 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
+      if (tune.sweep_order != 0 && tune.sweep_order != 3) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
       return 0;
     }
     if (&M == &Xt && Xth.nnz > 0 && tune.xt_overlap) {
