@@ -236,6 +236,11 @@ int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, in
 int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
                                int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece,
                                int xcd_group, mnmf_segments* out);
+/* The same with exact-length segments (exact != 0): a segment is closed after exactly seg_nnz nnz -- the piece is cut
+ * there and both parts get carry slots -- which is what the engine does for small matrices. */
+int mnmf_build_segments_exact(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
+                              int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece,
+                              int xcd_group, int exact, mnmf_segments* out);
 /* Tile stream of X^T (the most frequent words; DESIGN.md "tile stream"): piece_tile[i] = tile of piece i,
  * ascending.  seg_nnz > 0: segments of about seg_nnz nnz that never cross a tile; seg_nnz <= 0: every tile is cut
  * into -seg_nnz equal segments (pieces are cut at segment boundaries).  tile_first (n_tiles + 1 entries, caller

@@ -68,6 +68,8 @@ SIGNATURES = {
     "mnmf_build_segments": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(MnmfSegments)]),
     "mnmf_build_segments_pieces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int64, C.c_int, C.POINTER(MnmfSegments)]),
+    "mnmf_build_segments_exact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                            C.c_int64, C.c_int, C.c_int, C.POINTER(MnmfSegments)]),
     "mnmf_build_segments_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                             C.c_int64, C.c_int64, C.POINTER(MnmfSegments), C.c_void_p]),
     "mnmf_free_segments": (None, [C.POINTER(MnmfSegments)]),

@@ -250,6 +250,12 @@ int mnmf_build_segments(const int64_t* rowptr, int64_t rows, int64_t seg_nnz, in
 int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
                                int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece, int xcd_group,
                                mnmf_segments* out) {
+  return mnmf_build_segments_exact(piece_start, piece_row, piece_block, n_pieces, rows, seg_nnz, sub_piece, xcd_group, 0, out);
+}
+
+int mnmf_build_segments_exact(const int64_t* piece_start, const int32_t* piece_row, const int32_t* piece_block,
+                              int64_t n_pieces, int64_t rows, int64_t seg_nnz, int64_t sub_piece, int xcd_group,
+                              int exact, mnmf_segments* out) {
   if (!piece_start || !out || rows < 0 || n_pieces < 0 || (n_pieces > 0 && !piece_row)) return MNMF_EINVAL;
   HostPieces pc;
   pc.start.assign(piece_start, piece_start + n_pieces + 1);
@@ -258,7 +264,7 @@ int mnmf_build_segments_pieces(const int64_t* piece_start, const int32_t* piece_
   for (int64_t i = 0; i < n_pieces; ++i)
     if (pc.row[i] < 0 || pc.row[i] >= rows || pc.start[i + 1] <= pc.start[i]) return MNMF_EINVAL;
   HostSegments s;
-  build_segments_host(pc, rows, seg_nnz, sub_piece, s, piece_block ? xcd_group : 0);
+  build_segments_host(pc, rows, seg_nnz, sub_piece, s, piece_block ? xcd_group : 0, nullptr, 0, exact != 0);
   export_segments(s, out);
   return MNMF_OK;
 }

@@ -437,11 +437,12 @@ def confusion_lines(rows, strengths):
 
 
 def build_segments(rowptr=None, seg_nnz=64, sub_piece=512, *, piece_start=None, piece_row=None, piece_block=None,
-                   rows=None, xcd_group=0, n_tiles=None):
+                   rows=None, xcd_group=0, n_tiles=None, exact=False):
     """Host-only: the segment description the engine builds (no GPU needed; used by CPU tests).
     Give a CSR ``rowptr`` (one piece per non-empty row) or explicit pieces in processing order.
     With ``n_tiles`` the pieces describe the tile stream of X^T (``piece_block`` = tile of each piece) and the
-    result also holds ``tile_first``; ``seg_nnz <= 0`` then means -seg_nnz equal segments per tile."""
+    result also holds ``tile_first``; ``seg_nnz <= 0`` then means -seg_nnz equal segments per tile.  ``exact`` (explicit
+    pieces only): segments of exactly ``seg_nnz`` nnz, pieces cut at the boundary."""
     lib = _lib.load()
     s = _lib.MnmfSegments()
     tile_first = None
@@ -459,9 +460,9 @@ def build_segments(rowptr=None, seg_nnz=64, sub_piece=512, *, piece_start=None, 
         ps = np.ascontiguousarray(piece_start, dtype=np.int64)
         pr = np.ascontiguousarray(piece_row, dtype=np.int32)
         pb = None if piece_block is None else np.ascontiguousarray(piece_block, dtype=np.int32)
-        rc = lib.mnmf_build_segments_pieces(ps.ctypes.data, pr.ctypes.data, None if pb is None else pb.ctypes.data,
-                                            len(pr), int(rows), int(seg_nnz), int(sub_piece), int(xcd_group),
-                                            C.byref(s))
+        rc = lib.mnmf_build_segments_exact(ps.ctypes.data, pr.ctypes.data, None if pb is None else pb.ctypes.data,
+                                           len(pr), int(rows), int(seg_nnz), int(sub_piece), int(xcd_group),
+                                           int(bool(exact)), C.byref(s))
     if rc != 0:
         raise MnmfError(rc, "mnmf_build_segments")
     try:

@@ -368,3 +368,37 @@ def test_cached_engine_key_is_the_gpu_not_the_spelling():
     assert nmf._device_index(torch.device("cuda", 3)) == 3
     assert isinstance(nmf._device_index(None), int)
 
+
+
+@pytest.mark.parametrize("q,group", [(32, 0), (128, 0), (64, 16)])
+def test_segments_exact_length(q, group):
+    """Exact-length segments (small matrices): every segment holds exactly q nnz unless it ends a block or the stream;
+    cut pieces are summed from carry slots, everything still lands in its row."""
+    from manta_amd.engine import build_segments
+
+    rng = np.random.RandomState(q + group)
+    n_rows, n_blocks = 60, 11
+    rows, lens, blocks = [], [], []
+    for b in range(n_blocks):
+        for r in range(40):
+            if rng.rand() < 0.7:
+                rows.append(r)
+                lens.append(int(rng.randint(1, 700)))
+                blocks.append(b)
+    for r in range(40, 58):
+        rows.append(r)
+        lens.append(int(rng.randint(1, 90)))
+        blocks.append(-1)
+    start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz_block = np.repeat(np.array(blocks), lens)
+    seg = build_segments(piece_start=start, piece_row=np.array(rows), piece_block=np.array(blocks), rows=n_rows,
+                         seg_nnz=q, sub_piece=512, xcd_group=group, exact=True)
+    _check_cover(seg, np.repeat(np.array(rows), lens), n_rows, 512)
+    for a, n in zip(seg["seg_start"], seg["seg_len"]):
+        if n == 0:
+            continue
+        assert n <= q
+        end = a + n
+        if n < q:   # short only where the block changes or the stream ends (blocks matter only in the XCD-affine mode)
+            assert end == start[-1] or (group and nnz_block[end] != nnz_block[end - 1])
+    assert int(seg["seg_len"].sum()) == int(start[-1])
