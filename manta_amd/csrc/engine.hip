@@ -99,6 +99,7 @@ struct Tune {
   int exact_seg = -1;                 // segments of exactly q nnz (pieces cut at the boundary): -1 by size (ensure_segments), 0 never, 1 X^T blocked stream, 2 every stream
   int queue = 0;                      // X^T blocked stream as a persistent launch with per-lane-group segment queues (2: the plain X stream too)
   int queue_wgs = 0;                  // ... workgroups per CU; 0 = what the occupancy calculator says
+  int async_gram = 1;                 // sharded NMF: the k x k all-reduce of an iteration's end on a stream of its own, beside the next X^T.W
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
@@ -137,6 +138,7 @@ struct Tune {
     xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
+    async_gram = (int)geti("MNMF_ASYNC_GRAM", async_gram);
     queue = (int)geti("MNMF_QUEUE", queue);
     exact_seg = (int)geti("MNMF_EXACT_SEG", exact_seg);
     queue_wgs = (int)geti("MNMF_QUEUE_WGS", queue_wgs);
@@ -228,6 +230,9 @@ class Engine : public ImplBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    if (ev_comm_in) (void)hipEventDestroy(ev_comm_in);
+    if (ev_comm_out) (void)hipEventDestroy(ev_comm_out);
   }
 
   mnmf_ctx* ctx;
@@ -253,6 +258,8 @@ class Engine : public ImplBase {
 
   // the caller's stream, or the engine's side stream while the X^T tile stream is being enqueued (see spmm)
   hipStream_t side_stream = nullptr, st_override = nullptr;
+  hipStream_t comm_stream = nullptr;                 // small collectives that the next SpMM does not wait for (ensure_comm_stream)
+  hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t st() const { return st_override ? st_override : ctx->stream; }
   // leading dimension of every factor matrix: rows of up to 32 elements fill whole 128-byte lines
@@ -953,6 +960,20 @@ class Engine : public ImplBase {
   // engine, the side stream landed on the caller's queue and the overlap was gone (X^T.W 1.34 -> 1.86 ms at configs[1],
   // kernel trace of the RCCL rehearsal).  Streams of another priority come from another set of queues, whatever else
   // the process has created.
+  // A stream of its own (high priority) for the collectives whose result the next kernels on the solver's stream do not
+  // need: the all-reduce of [w.T@w | dW Gram] at the end of a sharded NMF iteration is only read by the H update, one
+  // X^T.W later.  The hook is handed this stream, so an RCCL collective runs beside the SpMM instead of before it.
+  int ensure_comm_stream() {
+    if (comm_stream) return 0;
+    int lo = 0, hi = 0;   // numerically lowest = highest priority
+    E_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (lo != hi) E_HIP(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, lo));
+    else E_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    E_HIP(hipEventCreateWithFlags(&ev_comm_in, hipEventDisableTiming));
+    E_HIP(hipEventCreateWithFlags(&ev_comm_out, hipEventDisableTiming));
+    return 0;
+  }
+
   int ensure_side_stream() {
     if (side_stream) return 0;
     int lo = 0, hi = 0;   // numerically lowest = highest priority
@@ -1645,6 +1666,7 @@ class Engine : public ImplBase {
     int64_t i = 0;
     int converged = 0;
     bool gw_valid = false;  // Gw holds this rank's w.T@w of the current w (left there by the previous w update)
+    bool gw_in_flight = false;  // ... and its all-reduce is still running on the communication stream
     LoopClock clk;
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
@@ -1677,6 +1699,10 @@ class Engine : public ImplBase {
       pt.mark(0);
       MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
       pt.mark(1);
+      if (gw_in_flight) {  // w.T@w of the previous w update: summed over the ranks beside the SpMM above
+        E_HIP(hipStreamWaitEvent(ctx->stream, ev_comm_out, 0));
+        gw_in_flight = false;
+      }
       if (sliced) {
         // every rank sums and updates one slice of the vocabulary, then the slices are gathered: the same bytes on
         // the wire as an all-reduce, the h update done once instead of n_ranks times, h identical on every rank
@@ -1712,15 +1738,31 @@ class Engine : public ImplBase {
       pt.mark(5);
       // sliced: the next iteration's w.T@w and this iteration's dW Gram in one collective (the dH Gram is computed by
       // every rank from the gathered h); otherwise w.T@w travels with the next k x V partial
-      if (sliced) MNMF_TRY(allreduce(Gw, (int64_t)ld * ld * (do_check ? 2 : 1)));
-      if (do_check) {
-        if (!sliced) MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
-        MNMF_TRY(fetch_begin(2 * (size_t)ld * ld));
-        MNMF_TRY(fetch_add(Gd, 2 * (size_t)ld * ld));
-        MNMF_TRY(fetch_commit());
-        pending = true;
-        pt.mark(6);
+      const bool async_gram = sliced && tune.async_gram;
+      if (async_gram) {  // the collective and the copy of the norms' Grams leave the solver's stream: the next X^T.W does not wait
+        MNMF_TRY(ensure_comm_stream());
+        E_HIP(hipEventRecord(ev_comm_in, ctx->stream));
+        E_HIP(hipStreamWaitEvent(comm_stream, ev_comm_in, 0));
+        st_override = comm_stream;
       }
+      int rc_comm = 0;
+      if (sliced) rc_comm = allreduce(Gw, (int64_t)ld * ld * (do_check ? 2 : 1));
+      if (rc_comm == 0 && do_check) {
+        if (!sliced) rc_comm = allreduce(Gd, (int64_t)ld * ld);
+        if (rc_comm == 0) rc_comm = fetch_begin(2 * (size_t)ld * ld);
+        if (rc_comm == 0) rc_comm = fetch_add(Gd, 2 * (size_t)ld * ld);
+        if (rc_comm == 0) rc_comm = fetch_commit();
+        pending = rc_comm == 0;
+      }
+      if (async_gram) {
+        st_override = nullptr;
+        if (rc_comm == 0) {
+          E_HIP(hipEventRecord(ev_comm_out, comm_stream));
+          gw_in_flight = true;
+        }
+      }
+      MNMF_TRY(rc_comm);
+      if (do_check) pt.mark(6);
       cw = 1 - cw;
       ch = 1 - ch;
       ++done;
@@ -1739,6 +1781,7 @@ class Engine : public ImplBase {
       }
       if (fixed <= 0 && done <= max_iter && w_norm < thr && h_norm < thr) converged = 1;   // :57 comes before :62
     }
+    if (comm_stream) E_HIP(hipStreamWaitEvent(ctx->stream, ev_comm_out, 0));   // nothing of this run is left on the communication stream
     MNMF_TRY(clock_stop(clk, stats));
     pt.collect(phase_ms);
     if (stats) std::memcpy(stats->phase_ms, phase_ms, sizeof(phase_ms));
@@ -1766,12 +1809,10 @@ class Engine : public ImplBase {
   // run: every number a problem sees is produced by the same operations in the same order as in its own run_nmf, so
   // each result is bit-identical to the single-k run (tests/test_gpu_sweep.py).  Each problem stops by the reference's
   // rule on its own norms (nmf_basic.py:52-62): its factors are copied out at that iteration while the others go on.
-  // Not for sharded contexts (the exchange would have to be per problem) and fp32 only; the Python side falls back to
-  // one run_nmf per k otherwise.
+  // fp64 alike with 16 doubles per line (sum(k) <= 16; dense_rk_mfma_f64_kernel takes the same column window).  Not for
+  // sharded contexts (the exchange would have to be per problem); the Python side falls back to one run_nmf per k.
   int run_nmf_sweep(int n, const int32_t* ks, void* const* Ws, void* const* Hs, const mnmf_opts* o, mnmf_stats* stats) override {
-    if constexpr (sizeof(T) != 4) {
-      return fail(MNMF_EINVAL, "run_nmf_sweep: batching is implemented for fp32 contexts");
-    } else {
+    {
       if (n < 1 || n > 32 || !ks || !Ws || !Hs) return fail(MNMF_EINVAL, "run_nmf_sweep: bad arguments");
       int sum = 0;
       std::vector<int> off(n);
@@ -1782,8 +1823,15 @@ class Engine : public ImplBase {
       }
       MNMF_TRY(check_ready(sum));
       const int ld = ld_of(sum);
-      if (sum > 32 || ld != 32 || !can_fuse(ld))
-        return fail(MNMF_EINVAL, "run_nmf_sweep: the topic counts of one batch must add up to at most 32 (one 128-byte factor row)");
+      constexpr int kLine = (int)(128 / sizeof(T));   // factor columns in one 128-byte row: 32 floats / 16 doubles
+      if (sum > kLine || ld != kLine || !can_fuse(ld))
+        return fail(MNMF_EINVAL, "run_nmf_sweep: the topic counts of one batch must add up to at most " + std::to_string(kLine) +
+                                     " (one 128-byte factor row)");
+      // the fused update of one problem: the same kernel a single run_nmf of that topic count takes
+      auto update = [&](const RkArgs<T>& a, T* gram_new, T* gram_diff) -> int {
+        if constexpr (sizeof(T) == 4) return rk_fused_nt<1>(RK_MU, a, gram_new, gram_diff);
+        else return rk64_nt<1>(RK_MU, a, gram_new, gram_diff);
+      };
       if (ctx->sharded()) return fail(MNMF_EINVAL, "run_nmf_sweep: not available on a sharded context");
       const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 10000;
       const int fixed = o ? o->fixed_iters : 0;
@@ -1890,8 +1938,8 @@ class Engine : public ImplBase {
         MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                    // every problem's (w.T @ in_mat)^T     :40
         for (int p = 0; p < n; ++p) {                                      // h update + h @ h.T + |dh| gram        :41-44, :53
           if (state[p]) continue;
-          RkArgs<float> a{Hc, Gw(p), nullptr, nullptr, Hc, Nh, Hn, V, ld, (float)eps, off[p], ks[p]};
-          MNMF_TRY(rk_fused_nt<1>(RK_MU, a, Gh(p), do_check ? Gd(p) + gel : nullptr));
+          RkArgs<T> a{Hc, Gw(p), nullptr, nullptr, Hc, Nh, Hn, V, ld, (T)eps, off[p], ks[p]};
+          MNMF_TRY(update(a, Gh(p), do_check ? Gd(p) + gel : nullptr));
         }
         MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                    // every problem's in_mat @ h.T         :45
         if (pending) {
@@ -1901,8 +1949,8 @@ class Engine : public ImplBase {
         }
         for (int p = 0; p < n; ++p) {                                      // w update + next w.T @ w + |dw| gram   :46-47, :39, :52
           if (state[p]) continue;
-          RkArgs<float> a{Wc, Gh(p), nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, (float)eps, off[p], ks[p]};
-          MNMF_TRY(rk_fused_nt<1>(RK_MU, a, Gw(p), do_check ? Gd(p) : nullptr));
+          RkArgs<T> a{Wc, Gh(p), nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, (T)eps, off[p], ks[p]};
+          MNMF_TRY(update(a, Gw(p), do_check ? Gd(p) : nullptr));
         }
         gw_valid = true;
         if (do_check) {

@@ -37,12 +37,20 @@ __global__ __launch_bounds__(256, 1) void dense_rk_mfma_f64_kernel(RkArgs<double
   const int j = lane & 15, q = lane >> 4;
   const int ld = a.ld;
   const unsigned rowb = (unsigned)ld * 8u;
-  const unsigned aoff = (unsigned)j * rowb + 32u * q;            // A operand: row j, 4 doubles at column 4q (+ 16c)
+  // Batched topic-count sweep (RkArgs::coff / kcols, dense.hpp): this call works on the kcols columns that start at
+  // column coff of the padded rows; G1 is the problem's own ld x ld matrix, zero beyond kcols.  The A operand is read
+  // at the column offset (8-byte aligned 16-byte buffer loads; what it reads beyond the problem's columns meets zero
+  // rows of G), numerator / old factor / output only in the problem's columns (a poisoned offset beyond any
+  // descriptor size reads 0 and drops the store).
+  constexpr unsigned kPoison = 0x40000000u;
+  const int kc = a.kcols > 0 ? a.kcols : ld;
+  const unsigned cob = 8u * (unsigned)a.coff;
+  const unsigned aoff = (unsigned)j * rowb + 32u * q + cob;      // A operand: row j, 4 doubles at column 4q (+ 16c)
   unsigned goff[NT], eoff[NT];                                   // G operand: row 4q (+16c + s), column 16t + j
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     goff[t] = (unsigned)(4 * q) * rowb + 8u * (16 * t + j);
-    eoff[t] = (unsigned)q * rowb + 8u * (16 * t + j);            // epilogue: row q (+ 4*reg), column 16t + j
+    eoff[t] = (16 * t + j < kc) ? (unsigned)q * rowb + 8u * (16 * t + j) + cob : kPoison;   // epilogue: row q (+ 4*reg), column 16t + j
   }
   f64x4 gnew[(FUSE & 1) ? NTRI : 1], gdif[(FUSE & 2) ? NTRI : 1];
   if (FUSE) {

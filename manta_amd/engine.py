@@ -270,7 +270,7 @@ class Engine:
     @_engine_stream
     def run_nmf_sweep(self, W0s, H0s, **kw):
         """Standard NMF for several topic counts in one pass over X per SpMM (mnmf_run_nmf_sweep): ``W0s[p]`` is
-        m x k_p, ``H0s[p]`` is k_p x V, the k_p of one call add up to at most 32 (fp32).  Returns a list of
+        m x k_p, ``H0s[p]`` is k_p x V, the k_p of one call add up to at most 32 (fp32) / 16 (fp64).  Returns a list of
         ``(W, H, stats)``, each bit-identical to ``run_nmf(W0s[p], H0s[p])`` on its own."""
         n = len(W0s)
         if n == 0 or n != len(H0s):

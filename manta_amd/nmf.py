@@ -166,7 +166,8 @@ def run_nmf(num_of_topics: int, sparse_matrix, init: Callable = nmf_initializati
     return out
 
 
-SWEEP_LINE = 32   # fp32 factor columns that share one padded 128-byte row (mnmf_run_nmf_sweep)
+SWEEP_LINE = 32   # fp32 factor columns that share one padded 128-byte row (mnmf_run_nmf_sweep); fp64: 16
+SWEEP_LINES = {"fp32": 32, "fp64": 16}
 
 
 def sweep_batches(ks, limit=SWEEP_LINE):
@@ -189,9 +190,10 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
                   max_iter: Optional[int] = None, fixed_iters: Optional[int] = None, check_every: int = 1,
                   starts=None, seed: int = 0, stats_out: Optional[list] = None) -> list:
     """``[run_nmf(k, sparse_matrix, ...) for k in topic_counts]`` -- the loop of OptimizationPipeline.run_optimization
-    (optimization_pipeline.py:105-136, 193-198) -- with the matrix uploaded once and, for standard NMF in fp32, the
-    topic counts that fit one padded factor row (sum <= 32) iterated TOGETHER: one pass over X per SpMM serves the
-    whole batch.  Every entry of the returned list equals the single ``run_nmf`` call bit for bit (same start).
+    (optimization_pipeline.py:105-136, 193-198) -- with the matrix uploaded once and, for standard NMF, the topic
+    counts that fit one padded 128-byte factor row (sum <= 32 in fp32, <= 16 in fp64, the drop-in's default dtype)
+    iterated TOGETHER: one pass over X per SpMM serves the whole batch.  Every entry of the returned list equals the
+    single ``run_nmf`` call bit for bit (same start).
 
     ``starts``: optional list of ``(W0, H0)`` per topic count; otherwise ``init`` is called once per count, in order,
     as the reference's loop would (``init="device"`` / ``"device_random"`` as in ``run_nmf``: the starts are then
@@ -204,7 +206,7 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
         raise ValueError("init must be a callable (csc, rank) -> (W0, H0) or one of the strings 'device', 'device_random'")
     results = [None] * len(ks)
     stats = [dict() for _ in ks]
-    batched = nmf_method == "nmf" and dtype == "fp32" and all(k > 0 for k in ks)
+    batched = nmf_method == "nmf" and dtype in SWEEP_LINES and all(k > 0 for k in ks)
     if nmf_method not in ("nmf", "pnmf", "nmtf"):
         raise ValueError(f"Unknown NMF method: {nmf_method}. Supported methods are: 'nmf', 'pnmf', 'nmtf'")
     extra = dict(check_every=check_every)
@@ -227,7 +229,7 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
                 starts = [idv.random_device(eng, k, seed=seed, with_s=True)[::2] for k in ks]   # run_nmf's draw: W, (S), H
             else:
                 starts = [idv.nndsvd_device(eng, k) for k in ks]
-        for batch in sweep_batches(ks):
+        for batch in sweep_batches(ks, SWEEP_LINES[dtype]):
             if len(batch) == 1:
                 i = batch[0]
                 W, H, st = eng.run_nmf(starts[i][0], starts[i][1], norm_thresh=norm_thresh, zero_threshold=zero_threshold, **extra)

@@ -82,16 +82,17 @@ def test_sweep_refuses_what_it_cannot_batch(eng, golden):
     e64 = Engine(dtype="fp64")
     try:
         e64.set_matrix(g["X"])
-        st = starts_for(g["X"], (5, 5), 2)
-        with pytest.raises(MnmfError):
+        st = starts_for(g["X"], (9, 8), 2)            # fp64: 16 doubles per 128-byte row
+        with pytest.raises(MnmfError) as ei:
             e64.run_nmf_sweep([a for a, _ in st], [b for _, b in st], fixed_iters=2)
+        assert ei.value.code == -1 and "at most 16" in str(ei.value)
     finally:
         e64.close()
 
 
 def test_run_nmf_sweep_drop_in_groups_and_falls_back(golden):
     """manta_amd.run_nmf_sweep == [run_nmf(k, X) for k in ks] (same starts), whatever the grouping: 5+10+15 go together,
-    20 alone; pnmf and fp64 run one by one."""
+    20 alone; pnmf runs one by one."""
     import manta_amd
     from manta_amd.nmf import sweep_batches
 
@@ -130,3 +131,52 @@ def test_run_nmf_sweep_with_device_starts(golden, init):
         assert np.array_equal(out["W"], want["W"]) and np.array_equal(out["H"], want["H"])
     with pytest.raises(ValueError):
         manta_amd.run_nmf_sweep(X, ks, init="host", dtype="fp32")
+
+
+@pytest.mark.parametrize("ks", [(5, 10), (7, 1, 3, 2), (16,), (8, 8), (6, 4, 6)])
+def test_sweep_fp64_bit_identical_to_single_runs(golden, ks):
+    """The batched sweep in float64 (the drop-in's default dtype): topic counts that add up to at most 16 share one
+    128-byte row; each result is bit-identical to its own run_nmf and within 1e-10 of the CPU oracle."""
+    from manta_amd.engine import Engine
+
+    e64 = Engine(dtype="fp64")
+    try:
+        g = golden("fixed_B_1000x1200_k10")
+        X = g["X"]
+        e64.set_matrix(X)
+        st = starts_for(X, ks, 100 + sum(ks))
+        got = e64.run_nmf_sweep([a for a, _ in st], [b for _, b in st], fixed_iters=20, force_check=True, zero_threshold=1e-5)
+        for (W0, H0), (W, H, s) in zip(st, got):
+            W1, H1, s1 = e64.run_nmf(W0, H0, fixed_iters=20, force_check=True, zero_threshold=1e-5)
+            assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
+            assert s.iters == s1.iters == 20 and s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
+        want = oc.basic_nmf(X, st[-1][0].copy(), st[-1][1].copy(), zero_threshold=1e-5, n_iter=20, check=False)
+        assert np.linalg.norm(host(got[-1][0]) - want["W"]) <= 1e-10 * np.linalg.norm(want["W"])
+        assert np.linalg.norm(host(got[-1][1]) - want["H"]) <= 1e-10 * np.linalg.norm(want["H"])
+        # staggered stopping under the reference's rule
+        g2 = golden("converged_D_600x500_k6_nmf")
+        e64.set_matrix(g2["X"])
+        st = starts_for(g2["X"], (5, 10), 77)
+        got = e64.run_nmf_sweep([a for a, _ in st], [b for _, b in st], norm_thresh=0.005, zero_threshold=1e-5)
+        for (W0, H0), (W, H, s) in zip(st, got):
+            W1, H1, s1 = e64.run_nmf(W0, H0, norm_thresh=0.005, zero_threshold=1e-5)
+            assert s.converged and s1.converged and s.iters == s1.iters
+            assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
+    finally:
+        e64.close()
+
+
+def test_run_nmf_sweep_default_dtype_batches(golden):
+    """run_nmf_sweep with the default dtype (fp64): 5 + 10 go together, 15 alone; equal to the single calls."""
+    import manta_amd
+
+    g = golden("converged_D_600x500_k6_nmf")
+    X = g["X"]
+    ks = [5, 10, 15]
+    st = starts_for(X, ks, 9)
+    stats = []
+    got = manta_amd.run_nmf_sweep(X, ks, norm_thresh=0.005, starts=st, stats_out=stats)
+    assert [s["batch"] for s in stats] == [[5, 10], [5, 10], [15]]
+    for k, (W0, H0), out in zip(ks, st, got):
+        want = manta_amd.run_nmf(k, X, norm_thresh=0.005, W0=W0, H0=H0)
+        assert np.array_equal(out["W"], want["W"]) and np.array_equal(out["H"], want["H"])

@@ -1,5 +1,6 @@
 """Topic-count sweep at BASELINE.json configs[0] (20k x 30k, density 0.003): three/four small-k NMF solves as separate
-run_nmf calls on the resident matrix against one batched mnmf_run_nmf_sweep call (200 iterations each, norms every iteration)."""
+run_nmf calls on the resident matrix against one batched mnmf_run_nmf_sweep call (200 iterations each, norms every iteration).
+usage: sweep_timing.py [c1|c2] [fp32|fp64]"""
 import json
 import os
 import sys
@@ -15,12 +16,13 @@ m, V, dens = (20_000, 30_000, 0.003) if len(sys.argv) < 2 or sys.argv[1] == "c1"
 N = 200 if m < 100_000 else 30
 dev = torch.device("cuda", 0)
 rowptr, col, val = zipf_tfidf_csr(m, V, dens, seed=1234, device=dev, dtype=torch.float64)
-eng = Engine(dtype="fp32")
+DT = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+eng = Engine(dtype=DT)
 eng.set_matrix(rowptr=rowptr, colidx=col, vals=val, shape=(m, V))
 g = torch.Generator(device=dev)
 g.manual_seed(1)
-out = {"matrix": f"{m}x{V} density {dens}", "iterations": N, "cases": []}
-for ks in ((5, 10, 15), (8, 8, 8, 8), (10, 20)):
+out = {"matrix": f"{m}x{V} density {dens}", "dtype": DT, "iterations": N, "cases": []}
+for ks in (((5, 10, 15), (8, 8, 8, 8), (10, 20)) if DT == "fp32" else ((5, 10), (4, 4, 4, 4), (8, 8))):
     st = [(torch.rand((m, k), generator=g, device=dev), torch.rand((k, V), generator=g, device=dev)) for k in ks]
     kw = dict(fixed_iters=N, force_check=True)
     for _ in range(2):                                  # warm both paths
