@@ -74,8 +74,8 @@ def pmc_traffic(config, dtype, direction):
     for r in rows:
         name = r.get("kernel", "")
         mm = re.search(r"spmm_stream_kernel<float, \d+, \d+, (\d)", name)
-        # X^T.W is several launches per iteration: the blocked stream, the tile stream and the carry fix-ups
-        if (mm and int(mm.group(1)) == direction) or (direction == 1 and "spmm_fixup" in name):
+        # X^T.W is several launches per iteration: the blocked stream, the tile stream, the sweep and the carry fix-ups
+        if (mm and int(mm.group(1)) == direction) or (direction == 1 and ("spmm_fixup" in name or "spmm_sweep" in name)):
             total += r["fetch_MB_corrected"] + r["write_MB"]
             hit = True
     if hit:
@@ -261,7 +261,7 @@ def main():
     # secondary bound: every nnz pulls one ld-wide factor row through the vector memory path;
     # tools/l1_probe.hip measured 28 TB/s for that access (16 B per lane, 4 rows per wave load) with every row in L1
     gather_bytes = nnz_loc * ld * sv
-    roofline = {"bound": "hbm", "kernel": "spmm_stream_kernel (" + ("X^T.W: blocked stream + tile stream + carry fix-ups" if dom == "spmm_xt" else "X.H^T") + ")",
+    roofline = {"bound": "hbm", "kernel": "spmm_stream_kernel (" + ("X^T.W: tile stream + blocked stream + sweep + carry fix-ups" if dom == "spmm_xt" else "X.H^T") + ")",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(dom_ms, 4),

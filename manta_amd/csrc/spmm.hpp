@@ -25,6 +25,9 @@
 #define MNMF_NT_LOAD(p) (*(p))
 #endif
 
+#ifndef MNMF_COLD_NT
+#define MNMF_COLD_NT 0   // experiment switch: 1 = every cold gather of the HOT mode non-temporal, 2 = only the tail rows
+#endif
 #ifndef MNMF_NT_STORE
 #define MNMF_NT_STORE 0
 #endif
@@ -335,9 +338,17 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
 #pragma unroll
             for (int w = 0; w < VPL; ++w) {
               const U4 l = *reinterpret_cast<const U4*>(reinterpret_cast<const char*>(lds) + lrow + lbytes[w]);
+#if MNMF_COLD_NT == 2   // experiment: rows far down the frequency order are gathered with the non-temporal policy
+              const bool tail = col >= (uint32_t)a.hot_rows * 16u;
+              U4 g, g2;
+              if (!hot && !tail) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(col, rowbytes) + cbytes[w], 0, 0);
+              if (tail) g2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(col, rowbytes) + cbytes[w], 0, 2);
+              const U4 sel = hot ? l : (tail ? g2 : g);
+#else
               U4 g;
-              if (!hot) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(col, rowbytes) + cbytes[w], 0, 0);
+              if (!hot) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, __umul24(col, rowbytes) + cbytes[w], 0, MNMF_COLD_NT ? 2 : 0);
               const U4 sel = hot ? l : g;
+#endif
               __builtin_memcpy(&b[u][w], &sel, sizeof(VT));
             }
           } else {
