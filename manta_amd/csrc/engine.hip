@@ -60,7 +60,7 @@ struct Tune {
   int xcd_affinity = 1;               // order X^T segments so that one XCD works on one document block
   int ld_align = 16;                  // leading-dimension granule (elements) for k > 32
   int permute_vocab = 1;              // renumber vocabulary rows by descending document frequency
-  int64_t hot_lds_bytes = 128 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off)
+  int64_t hot_lds_bytes = 152 << 10;  // LDS given to the most frequent rows of H^T in the X.H^T SpMM (0: off; 96 / 128 / 152 KiB: X.H^T 1.175 / 1.157 / 1.145 ms at configs[1])
   int xt_hot_words = -1;              // X^T: this many of the most frequent words go through LDS tiles of W (0: none; -1: 512; 256 when a tile holds fewer than 256 documents, 1024 from 1024)
   int64_t tile_lds_bytes = 156 << 10; // LDS budget of the W tiles of one CU (divided by tile_wgs_per_cu)
   int tile_min_rows = 128;            // tile stream only if a tile holds at least this many documents (174-document tiles: X^T.W -10 % at k = 100 fp64; 93: +6 %)
