@@ -99,6 +99,8 @@ struct Tune {
   int exact_seg = -1;                 // segments of exactly q nnz (pieces cut at the boundary): -1 by size (ensure_segments), 0 never, 1 X^T blocked stream, 2 every stream
   int queue = 0;                      // X^T blocked stream as a persistent launch with per-lane-group segment queues (2: the plain X stream too)
   int queue_wgs = 0;                  // ... workgroups per CU; 0 = what the occupancy calculator says
+  int early_exchange = 1;             // sharded NMF: exchange the rows of the less frequent words beside the tile stream of X^T.W
+  int early_check = 0;                // tests: fail instead of falling back when the early exchange cannot be taken
   int async_gram = 1;                 // sharded NMF: the k x k all-reduce of an iteration's end on a stream of its own, beside the next X^T.W
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
@@ -139,6 +141,8 @@ struct Tune {
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
     async_gram = (int)geti("MNMF_ASYNC_GRAM", async_gram);
+    early_exchange = (int)geti("MNMF_EARLY_EXCHANGE", early_exchange);
+    early_check = (int)geti("MNMF_EARLY_CHECK", early_check);
     queue = (int)geti("MNMF_QUEUE", queue);
     exact_seg = (int)geti("MNMF_EXACT_SEG", exact_seg);
     queue_wgs = (int)geti("MNMF_QUEUE_WGS", queue_wgs);
@@ -233,6 +237,9 @@ class Engine : public ImplBase {
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (ev_comm_in) (void)hipEventDestroy(ev_comm_in);
     if (ev_comm_out) (void)hipEventDestroy(ev_comm_out);
+    if (ev_cold) (void)hipEventDestroy(ev_cold);
+    if (ev_hot) (void)hipEventDestroy(ev_hot);
+    if (ev_h_done) (void)hipEventDestroy(ev_h_done);
   }
 
   mnmf_ctx* ctx;
@@ -260,6 +267,9 @@ class Engine : public ImplBase {
   hipStream_t side_stream = nullptr, st_override = nullptr;
   hipStream_t comm_stream = nullptr;                 // small collectives that the next SpMM does not wait for (ensure_comm_stream)
   hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
+  hipEvent_t ev_cold = nullptr, ev_hot = nullptr, ev_h_done = nullptr;   // early exchange of a sharded NMF iteration
+  bool xt_layout_only = false;          // spmm(Xt, ...) stops after the streams are laid out
+  hipEvent_t xt_cold_event = nullptr;   // set around spmm(Xt, ...): cold streams first, this event, then the tile stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t st() const { return st_override ? st_override : ctx->stream; }
   // leading dimension of every factor matrix: rows of up to 32 elements fill whole 128-byte lines
@@ -892,10 +902,25 @@ class Engine : public ImplBase {
         // occupy the CUs (C2 shards of 500k / 250k / 125k documents +13 / +11 / +5 %, 60k documents -4 %)
         const int64_t min_rows = tune.tile_min_rows, min_tiles = (int64_t)tune.tile_min_tiles_pct * n_cus / 100;
         if (tile_rows < min_rows || n_hot < 8 || cdiv(m, tile_rows) < std::max<int64_t>(min_tiles, 4)) n_hot = 0;
+        // sharded: the hot rows are an exchange range of their own (early exchange, run_nmf): a whole number of rows per rank
+        if (ctx->n_ranks > 1) n_hot -= n_hot % ctx->n_ranks;
       }
       // rare words: synchronised sweep with LDS accumulators (one vector per lane only)
       const size_t sweep_rb = (vmap() && tune.sweep > 0 && (vpl == 1 || lpr == 16) && !tune.force_wide) ? (size_t)lds_ld * sizeof(T) : 0;
       MNMF_TRY(ensure_xt(bs, n_hot, tile_rows, sweep_rb));
+      if (xt_layout_only) return 0;   // agree_early_exchange: only the streams' layout is wanted
+    }
+    if (&M == &Xt && xt_cold_event != nullptr) {
+      // Early exchange (sharded NMF): the streams of the less frequent words first -- their rows, all of `out` from row
+      // Xth.n_hot on, are final when xt_cold_event fires -- then the tile stream of the most frequent words, beside
+      // which the caller exchanges the rows that are done.  One after the other on the caller's stream.
+      MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 1));
+      if (Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
+      if (Xt.nnz > 0) MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      if (Xs.nnz > 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
+      E_HIP(hipEventRecord(xt_cold_event, ctx->stream));
+      if (Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
+      return 0;
     }
     if (&M == &Xt && Xs.nnz > 0) {
       // Three streams of X^T: sweep (rare words; LDS accumulators, needs its workgroups resident together and in step,
@@ -971,6 +996,9 @@ class Engine : public ImplBase {
     else E_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
     E_HIP(hipEventCreateWithFlags(&ev_comm_in, hipEventDisableTiming));
     E_HIP(hipEventCreateWithFlags(&ev_comm_out, hipEventDisableTiming));
+    E_HIP(hipEventCreateWithFlags(&ev_cold, hipEventDisableTiming));
+    E_HIP(hipEventCreateWithFlags(&ev_hot, hipEventDisableTiming));
+    E_HIP(hipEventCreateWithFlags(&ev_h_done, hipEventDisableTiming));
     return 0;
   }
 
@@ -1447,8 +1475,11 @@ class Engine : public ImplBase {
   // live columns on the wire only when at least a quarter of a padded row is padding (as allreduce_rows)
   bool pack_rows(int k, int ld) const { return tune.pack_exchange && (ld - k) * 4 >= ld; }
   // buf (padded_V x ld): every rank holds a partial; afterwards this rank's slice holds the sum over ranks
-  int reduce_scatter_rows(T* buf, int k, int ld) {
-    const int64_t Vs = slice_rows(), Vp = padded_V();
+  int reduce_scatter_rows(T* buf, int k, int ld) { return reduce_scatter_range(buf, slice_rows(), k, ld); }
+  // the same for a row range of n_ranks x Vs rows that starts at buf (rank r receives rows [r * Vs, (r + 1) * Vs) of it)
+  int reduce_scatter_range(T* buf, int64_t Vs, int k, int ld) {
+    const int64_t Vp = Vs * ctx->n_ranks;
+    if (Vs <= 0) return 0;
     if (!pack_rows(k, ld)) return collective(MNMF_COMM_REDUCE_SCATTER, buf, Vs * ld);
     E_HIP(ar_pack.ensure((size_t)Vp * k * sizeof(T)));
     T* q = ar_pack.template as<T>();
@@ -1461,8 +1492,10 @@ class Engine : public ImplBase {
     return 0;
   }
   // buf (padded_V x ld): this rank's slice is current; afterwards every slice holds its owner's rows
-  int all_gather_rows(T* buf, int k, int ld) {
-    const int64_t Vs = slice_rows(), Vp = padded_V();
+  int all_gather_rows(T* buf, int k, int ld) { return all_gather_range(buf, slice_rows(), k, ld); }
+  int all_gather_range(T* buf, int64_t Vs, int k, int ld) {
+    const int64_t Vp = Vs * ctx->n_ranks;
+    if (Vs <= 0) return 0;
     if (!pack_rows(k, ld)) return collective(MNMF_COMM_ALLGATHER, buf, Vs * ld);
     E_HIP(ar_pack.ensure((size_t)Vp * k * sizeof(T)));
     T* q = ar_pack.template as<T>();
@@ -1623,6 +1656,33 @@ class Engine : public ImplBase {
   }
 
   // ------------------------------------------------------------------ loop A
+  // Early exchange: every rank prepares its X^T streams, then the ranks sum (have a tile stream ? 1 : 0, its word
+  // count): the schedule is taken only if all of them have one with the same number of words (the word count follows
+  // from the shapes, the decision to use the tile stream from the local document count).
+  int agree_early_exchange(int ld, int64_t& eh) {
+    eh = 0;
+    constexpr int VEC = VecOf<T>::N;
+    if (ld % VEC != 0 || ld / VEC > 128) return 0;
+    xt_layout_only = true;
+    const int r = spmm(Xt, nullptr, ld, nullptr);
+    xt_layout_only = false;
+    MNMF_TRY(r);
+    const int64_t mine = (Xth.nnz > 0 && Xth.n_hot > 0 && Xth.n_hot % ctx->n_ranks == 0 && Xth.n_hot < V) ? Xth.n_hot : 0;
+    E_HIP(small.ensure(4 * sizeof(T)));
+    MNMF_TRY(pinned(4));
+    T h[2] = {(T)(mine > 0 ? 1 : 0), (T)mine};
+    E_HIP(hipMemcpyAsync(small.p, h, sizeof(h), hipMemcpyHostToDevice, st()));
+    E_HIP(hipStreamSynchronize(st()));   // h is on the stack
+    MNMF_TRY(allreduce(small.template as<T>(), 2));
+    E_HIP(hipMemcpyAsync(h, small.p, sizeof(h), hipMemcpyDeviceToHost, st()));
+    E_HIP(hipStreamSynchronize(st()));
+    if (mine > 0 && (int64_t)std::llround((double)h[0]) == ctx->n_ranks && (int64_t)std::llround((double)h[1]) == mine * ctx->n_ranks) {
+      MNMF_TRY(ensure_comm_stream());
+      eh = mine;
+    }
+    return 0;
+  }
+
   int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
     MNMF_TRY(check_ready(k));
     const int ld = ld_of(k);
@@ -1661,6 +1721,16 @@ class Engine : public ImplBase {
     }
     MNMF_TRY(load_W(W, k, ld, Wb[0].template as<T>()));
     MNMF_TRY(load_H(H, k, ld, Hb[0].template as<T>()));
+    // Early exchange: the rows of X^T.W that belong to the less frequent words -- all but the
+    // Xth.n_hot rows of the tile stream, i.e. nearly all of the k x V bytes -- are final before the tile stream starts;
+    // their reduce-scatter, this rank's share of the h update and the all-gather run on the communication stream beside
+    // the tile kernel.  Every rank must take the same schedule with the same row ranges: agreed here.
+    int64_t eh = 0;   // rows of the hot range (a multiple of the rank count); 0: the plain schedule
+    if (sliced && tune.early_exchange) {
+      MNMF_TRY(agree_early_exchange(ld, eh));
+      if (eh == 0 && tune.early_check) return fail(MNMF_ESTATE, "nmf: the early exchange was expected (MNMF_EARLY_CHECK) but the ranks do not all have a tile stream");
+    }
+    const int64_t Vs_h = eh / ctx->n_ranks, Vs_c = eh > 0 ? (Vp - eh) / ctx->n_ranks : 0;
     int cw = 0, ch = 0;
     double w_norm = INFINITY, h_norm = INFINITY;
     int64_t i = 0;
@@ -1697,13 +1767,46 @@ class Engine : public ImplBase {
         if (sliced) MNMF_TRY(allreduce(Gw, (int64_t)ld * ld));
       }
       pt.mark(0);
-      MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                   // (w.T @ in_mat)^T    :40
+      if (eh > 0) {
+        xt_cold_event = ev_cold;
+        const int r = spmm(Xt, Wc, ld, Nh);                             // (w.T @ in_mat)^T    :40, cold rows first
+        xt_cold_event = nullptr;
+        MNMF_TRY(r);
+        E_HIP(hipEventRecord(ev_hot, ctx->stream));
+      } else {
+        MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                 // (w.T @ in_mat)^T    :40
+      }
       pt.mark(1);
       if (gw_in_flight) {  // w.T@w of the previous w update: summed over the ranks beside the SpMM above
         E_HIP(hipStreamWaitEvent(ctx->stream, ev_comm_out, 0));
         gw_in_flight = false;
       }
-      if (sliced) {
+      if (eh > 0) {
+        // two row ranges, each cut into one slice per rank: [eh, Vp) as soon as the cold streams are done (the tile kernel
+        // is still running on the solver's stream), then [0, eh).  Everything here is enqueued on the communication stream.
+        E_HIP(hipStreamWaitEvent(comm_stream, ev_cold, 0));
+        st_override = comm_stream;
+        int r = 0;
+        for (int range = 0; range < 2 && r == 0; ++range) {
+          const int64_t base = range == 0 ? eh : 0, Vr = range == 0 ? Vs_c : Vs_h;
+          if (range == 1) {
+            const hipError_t e = hipStreamWaitEvent(comm_stream, ev_hot, 0);
+            if (e != hipSuccess) { r = fail(MNMF_EHIP, "early exchange: hipStreamWaitEvent failed"); break; }
+          }
+          const int64_t lo = base + Vr * ctx->rank;                                   // this rank's rows of the range
+          const int64_t rows = std::max<int64_t>(0, std::min<int64_t>(Vr, V - lo));
+          r = reduce_scatter_range(Nh + (size_t)base * ld, Vr, k, ld);
+          if (r == 0 && rows > 0)
+            r = rk(RK_MU, Hc + (size_t)lo * ld, Gw, nullptr, nullptr, Hc + (size_t)lo * ld, Nh + (size_t)lo * ld, Hn + (size_t)lo * ld, rows, ld, eps);   // :41-42
+          if (r == 0) r = all_gather_range(Hn + (size_t)base * ld, Vr, k, ld);
+        }
+        if (r == 0 && hipEventRecord(ev_h_done, comm_stream) != hipSuccess) r = fail(MNMF_EHIP, "early exchange: hipEventRecord failed");
+        st_override = nullptr;
+        MNMF_TRY(r);
+        E_HIP(hipStreamWaitEvent(ctx->stream, ev_h_done, 0));
+        MNMF_TRY(gram(Hn, nullptr, Hn, nullptr, V, ld, false, Gh));                                     // :44
+        if (do_check) MNMF_TRY(gram(Hn, Hc, Hn, Hc, V, ld, true, Gd + (size_t)ld * ld));                // :53
+      } else if (sliced) {
         // every rank sums and updates one slice of the vocabulary, then the slices are gathered: the same bytes on
         // the wire as an all-reduce, the h update done once instead of n_ranks times, h identical on every rank
         MNMF_TRY(reduce_scatter_rows(Nh, k, ld));

@@ -91,6 +91,34 @@ def emulate_rsag(method, X, W, H, S, N):
     return {"W": W, "S": S, "H": Ht[:V].T.copy()}
 
 
+def emulate_early(X, W, H, N, hot=96):
+    """engine.hip run_nmf with the early exchange: the vocabulary rows are two ranges -- [hot, Vp),
+    the rows of the less frequent words, exchanged first (on the GPU: beside the tile stream that is still producing the
+    hot rows), then [0, hot) -- each cut into one slice per rank: reduce-scatter, this rank's rows updated, all-gather.
+    `hot` is rounded down to a multiple of the rank count, as the engine does."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    k, V = H.shape
+    hot -= hot % world
+    Vp = world * (-(-V // world))
+    Ht = np.concatenate([H.T.copy(), np.zeros((Vp - V, k))])
+    for _ in range(N):
+        wtw = allreduce(W.T @ W)
+        part = np.concatenate([X.T @ W, np.zeros((Vp - V, k))])
+        new = np.empty_like(Ht)
+        for base, rows in ((hot, Vp - hot), (0, hot)):            # cold range first
+            Vr = rows // world
+            num = reduce_scatter_rows(part[base:base + rows], rank, world)
+            lo = base + Vr * rank
+            n_own = max(0, min(Vr, V - lo))
+            mine = Ht[lo:lo + Vr].copy()
+            mine[:n_own] = mine[:n_own] * (num[:n_own] / (mine[:n_own] @ wtw + oc.NMF_EPS))
+            new[base:base + rows] = all_gather_rows(mine, world)
+        Ht = new
+        Hn = Ht[:V]
+        W = W * ((X @ Hn) / (W @ (Hn.T @ Hn) + oc.NMF_EPS))
+    return {"W": W, "H": Ht[:V].T.copy()}
+
+
 def emulate(method, X, W, H, S, N):
     """Per-rank schedule of engine.hip (run_nmf / run_pnmf / run_nmtf) with its exchange points."""
     if method == "nmf":
@@ -131,6 +159,9 @@ def emulate(method, X, W, H, S, N):
 
 def main():
     mode, method = sys.argv[1], sys.argv[2]
+    if os.environ.get("MNMF_TEST_DUMP_AFTER"):      # where is every rank, if the run is still going after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MNMF_TEST_DUMP_AFTER"]), exit=True)
     if mode.startswith("nccl1"):
         # one rank, RCCL backend: the collectives are trivial, but they are the real calls (in place, on tensors that
         # alias the engine's buffers, ordered against the engine's stream) -- all a one-GPU box can rehearse of them
@@ -152,6 +183,9 @@ def main():
         want = oc.nmtf_core(X, W0, S0, H0, zero_threshold=0.0, n_iter=N, check=False)
     if mode == "emulate":
         got = emulate(method, Xl.tocsr(), W0[lo:hi].copy(), H0.copy(), S0.copy(), N)
+        tol = 1e-11
+    elif mode == "emulate_early":
+        got = emulate_early(Xl.tocsr(), W0[lo:hi].copy(), H0.copy(), N)
         tol = 1e-11
     elif mode == "emulate_rsag":
         got = emulate_rsag(method, Xl.tocsr(), W0[lo:hi].copy(), H0.copy(), S0.copy(), N)

@@ -58,6 +58,39 @@ def test_reduce_scatter_schedule_three_ranks_uneven_slices():
     launch(["emulate_rsag", "nmtf"], 29656, nproc=7)     # 1200 = 7 * 172 - 4: the last slice is padded
 
 
+@pytest.mark.parametrize("nproc", [2, 3, 4])
+def test_early_exchange_schedule_gloo_cpu(nproc):
+    """The early exchange of a sharded NMF iteration (two row ranges, the cold one first) in numpy over gloo: equal to
+    the unsharded oracle to 1e-11 with 2, 3 (hot range rounded down to 96 -> 96, 1104 cold rows = 3 x 368) and 4 ranks."""
+    launch(["emulate_early", "nmf"], 29681 + nproc, nproc=nproc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,dtype", [(2, "fp64"), (3, "fp32"), (4, "fp32")])
+def test_sharded_engine_early_exchange(nproc, dtype):
+    """The real engine through the early exchange: the tile stream of X^T.W forced on for the test-sized matrix (it is
+    what leaves the cold rows final early), ranks sharing the one GPU over gloo; results within the tolerances of the
+    unsharded oracle, H bit-identical across ranks.  MNMF_EARLY_EXCHANGE=0 must give the plain sliced schedule."""
+    tile = dict(MNMF_HOT_MIN_NNZ="0", MNMF_TILE_MIN_ROWS="1", MNMF_TILE_MIN_TILES_PCT="0", MNMF_XT_HOT_WORDS="100",
+                MNMF_TILE_LDS_BYTES="4096", MNMF_EARLY_CHECK="1")
+    launch(["engine", "nmf", dtype, "check"], 29690 + nproc, nproc=nproc, **tile)
+    if nproc == 2:
+        # The plain sliced schedule on the same streams.  Only with two ranks: it runs the tile stream and the blocked
+        # stream on two HIP streams per process, and four processes with three streams each on ONE GPU oversubscribe
+        # its hardware queues -- cross-stream waits then stall for good (seen with 4 ranks, not with MNMF_XT_OVERLAP=0;
+        # a one-process-per-GPU run has no such sharing).
+        launch(["engine", "nmf", dtype, "check"], 29695 + nproc, nproc=nproc, MNMF_EARLY_EXCHANGE="0", **tile)
+
+
+@pytest.mark.gpu
+def test_rccl_early_exchange_in_a_group_of_one():
+    """The early exchange with the RCCL hook in a group of one rank (MNMF_RS_AG=2): the collectives on the communication
+    stream, ordered against the solver's stream by events, leave the oracle's result."""
+    launch(["nccl1", "nmf", "fp32", "check"], 29699, nproc=1, MNMF_RS_AG="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+           MNMF_HOT_MIN_NNZ="0", MNMF_TILE_MIN_ROWS="1", MNMF_TILE_MIN_TILES_PCT="0", MNMF_XT_HOT_WORDS="100",
+           MNMF_TILE_LDS_BYTES="4096", MNMF_EARLY_CHECK="1")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["fp64", "fp32"])
 @pytest.mark.parametrize("method", ["nmf", "pnmf", "nmtf"])
