@@ -99,7 +99,9 @@ struct Tune {
   int exact_seg = -1;                 // segments of exactly q nnz (pieces cut at the boundary): -1 by size (ensure_segments), 0 never, 1 X^T blocked stream, 2 every stream
   int queue = 0;                      // X^T blocked stream as a persistent launch with per-lane-group segment queues (2: the plain X stream too)
   int queue_wgs = 0;                  // ... workgroups per CU; 0 = what the occupancy calculator says
-  int early_exchange = 1;             // sharded NMF: exchange the rows of the less frequent words beside the tile stream of X^T.W
+  int early_exchange = 0;             // sharded NMF: exchange the rows of the less frequent words beside the tile stream of X^T.W.
+                                      // Off: it gives up the tile || blocked overlap, which costs what it can hide (one rank's compute at the
+                                      // configs[1] shard sizes of 1 / 4 / 8 ranks: 363 -> 324, 1101 -> 996, 1765 -> 1608 it/s)
   int early_check = 0;                // tests: fail instead of falling back when the early exchange cannot be taken
   int async_gram = 1;                 // sharded NMF: the k x k all-reduce of an iteration's end on a stream of its own, beside the next X^T.W
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1

@@ -70,10 +70,10 @@ def test_early_exchange_schedule_gloo_cpu(nproc):
 def test_sharded_engine_early_exchange(nproc, dtype):
     """The real engine through the early exchange: the tile stream of X^T.W forced on for the test-sized matrix (it is
     what leaves the cold rows final early), ranks sharing the one GPU over gloo; results within the tolerances of the
-    unsharded oracle, H bit-identical across ranks.  MNMF_EARLY_EXCHANGE=0 must give the plain sliced schedule."""
+    unsharded oracle, H bit-identical across ranks.  MNMF_EARLY_EXCHANGE=0 (the default) must give the plain sliced schedule."""
     tile = dict(MNMF_HOT_MIN_NNZ="0", MNMF_TILE_MIN_ROWS="1", MNMF_TILE_MIN_TILES_PCT="0", MNMF_XT_HOT_WORDS="100",
                 MNMF_TILE_LDS_BYTES="4096", MNMF_EARLY_CHECK="1")
-    launch(["engine", "nmf", dtype, "check"], 29690 + nproc, nproc=nproc, **tile)
+    launch(["engine", "nmf", dtype, "check"], 29690 + nproc, nproc=nproc, MNMF_EARLY_EXCHANGE="1", **tile)
     if nproc == 2:
         # The plain sliced schedule on the same streams.  Only with two ranks: it runs the tile stream and the blocked
         # stream on two HIP streams per process, and four processes with three streams each on ONE GPU oversubscribe
@@ -88,7 +88,7 @@ def test_rccl_early_exchange_in_a_group_of_one():
     stream, ordered against the solver's stream by events, leave the oracle's result."""
     launch(["nccl1", "nmf", "fp32", "check"], 29699, nproc=1, MNMF_RS_AG="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
            MNMF_HOT_MIN_NNZ="0", MNMF_TILE_MIN_ROWS="1", MNMF_TILE_MIN_TILES_PCT="0", MNMF_XT_HOT_WORDS="100",
-           MNMF_TILE_LDS_BYTES="4096", MNMF_EARLY_CHECK="1")
+           MNMF_TILE_LDS_BYTES="4096", MNMF_EARLY_CHECK="1", MNMF_EARLY_EXCHANGE="1")
 
 
 @pytest.mark.gpu
