@@ -119,11 +119,29 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
   T* lds = reinterpret_cast<T*>(mnmf_smem);
   const int ld = a.ld;
   if (HOT) {
+    // the hot rows are the first rows of B, contiguous in memory: SU loads in flight per thread before the first LDS
+    // write, on a descriptor of exactly those rows (past their end a load returns zeros, which are not stored)
+    constexpr int SU = 6;
     const int nvr = ld / VEC;
     const int total = a.hot_rows * nvr;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const int r = i / nvr, c = (i - r * nvr) * VEC;
-      *reinterpret_cast<VT*>(lds + (size_t)r * a.lds_ld + c) = *reinterpret_cast<const VT*>(a.B + (size_t)r * ld + c);
+    const bool same = a.lds_ld == ld;
+    __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.B), 0, (uint32_t)total * 16u, 0x00020000);
+    for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * SU) {
+      U4 t[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (uint32_t)(i0 + u * (int)blockDim.x) * 16u, 0, 0);
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i < total) {
+          uint32_t o = (uint32_t)i * 16u;
+          if (!same) {
+            const int r = i / nvr;
+            o = ((uint32_t)r * (uint32_t)a.lds_ld + (uint32_t)(i - r * nvr) * VEC) * (uint32_t)sizeof(T);
+          }
+          *reinterpret_cast<U4*>(reinterpret_cast<char*>(lds) + o) = t[u];
+        }
+      }
     }
     __syncthreads();
   }
