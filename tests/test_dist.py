@@ -66,7 +66,7 @@ def test_early_exchange_schedule_gloo_cpu(nproc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,dtype", [(2, "fp64"), (3, "fp32"), (4, "fp32")])
+@pytest.mark.parametrize("nproc,dtype", [(2, "fp64"), (3, "fp32")])   # 4 ranks on ONE GPU: minutes of queue stalls, see below
 def test_sharded_engine_early_exchange(nproc, dtype):
     """The real engine through the early exchange: the tile stream of X^T.W forced on for the test-sized matrix (it is
     what leaves the cold rows final early), ranks sharing the one GPU over gloo; results within the tolerances of the
@@ -77,8 +77,9 @@ def test_sharded_engine_early_exchange(nproc, dtype):
     if nproc == 2:
         # The plain sliced schedule on the same streams.  Only with two ranks: it runs the tile stream and the blocked
         # stream on two HIP streams per process, and four processes with three streams each on ONE GPU oversubscribe
-        # its hardware queues -- cross-stream waits then stall for good (seen with 4 ranks, not with MNMF_XT_OVERLAP=0;
-        # a one-process-per-GPU run has no such sharing).
+        # its hardware queues -- cross-stream waits then stall (the early exchange with 4 ranks took 124 s instead of 4,
+        # the plain schedule did not finish; neither with MNMF_XT_OVERLAP=0).  A one-process-per-GPU run has no such
+        # sharing; four ranks are covered by the gloo emulation above and by test_sharded_engine_four_ranks.
         launch(["engine", "nmf", dtype, "check"], 29695 + nproc, nproc=nproc, MNMF_EARLY_EXCHANGE="0", **tile)
 
 
