@@ -52,6 +52,15 @@ struct DevBuf {
 };
 
 // Tunables (environment overrides are for experiments; defaults are what the benchmarks use).
+// sets Engine::data_cols for the duration of a solver call
+struct ColsGuard {
+  int& ref;
+  ColsGuard(int& r, int k) : ref(r) { ref = k; }
+  ~ColsGuard() { ref = 0; }
+  ColsGuard(const ColsGuard&) = delete;
+  ColsGuard& operator=(const ColsGuard&) = delete;
+};
+
 struct Tune {
   int64_t x_q = 512;                  // target nnz per segment, X stream with the LDS-hot kernel (256: configs[1] X.H^T +4 %)
   int64_t x_q_plain = 256;            // ... with the plain kernel (512: X.H^T +7..10 % at 1e7-2.5e7 nnz, equal elsewhere)
@@ -104,6 +113,7 @@ struct Tune {
                                       // configs[1] shard sizes of 1 / 4 / 8 ranks: 363 -> 324, 1101 -> 996, 1765 -> 1608 it/s)
   int early_check = 0;                // tests: fail instead of falling back when the early exchange cannot be taken
   int async_gram = 1;                 // sharded NMF: the k x k all-reduce of an iteration's end on a stream of its own, beside the next X^T.W
+  int lds_compact = 1;                // LDS images of factor rows hold only the columns with data (spmm())
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
@@ -142,6 +152,7 @@ struct Tune {
     xt_long_floor = geti("MNMF_XT_LONG_FLOOR", xt_long_floor);
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
+    lds_compact = (int)geti("MNMF_LDS_COMPACT", lds_compact);
     async_gram = (int)geti("MNMF_ASYNC_GRAM", async_gram);
     early_exchange = (int)geti("MNMF_EARLY_EXCHANGE", early_exchange);
     early_check = (int)geti("MNMF_EARLY_CHECK", early_check);
@@ -270,6 +281,7 @@ class Engine : public ImplBase {
   hipStream_t comm_stream = nullptr;                 // small collectives that the next SpMM does not wait for (ensure_comm_stream)
   hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
   hipEvent_t ev_cold = nullptr, ev_hot = nullptr, ev_h_done = nullptr;   // early exchange of a sharded NMF iteration
+  int data_cols = 0;                    // columns of the factors that hold data in the running solver call (0: all ld), ColsGuard
   bool xt_layout_only = false;          // spmm(Xt, ...) stops after the streams are laid out
   hipEvent_t xt_cold_event = nullptr;   // set around spmm(Xt, ...): cold streams first, this event, then the tile stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -783,6 +795,7 @@ class Engine : public ImplBase {
                   M.cols.template as<uint32_t>(), M.vals.template as<T>(), M.dest.template as<int32_t>(), M.n_dest,
                   B, ld, nc, out, carry, hot, lds_ld, wide ? 0u : (uint32_t)tab_bytes,
                   M.tile_first.template as<int32_t>(), (int)M.n_tiles, M.tile_rows, M.tab_rows};
+    a.kreal = (c0 == 0 && lds_ld < ld) ? std::min(nc, lds_ld) : nc;   // compact LDS images (spmm(): lds_compact)
     if (&M == &Xth) {
       if (waves > 0) {  // tile stream: every gather is an LDS read (indices are local to the tile)
         auto kern = spmm_stream_kernel<T, LPR, VPL, 1, SPMM_TILE, false>;
@@ -879,7 +892,11 @@ class Engine : public ImplBase {
     // tiles) that never paid at 32 lanes (hot_x_threshold)
     if (tune.two_vec && sizeof(T) == 8 && lpr == 32) lpr = 16, vpl = 2;
     const int ng = kWave / lpr;
-    const int lds_ld = ld + lds_pad_for(ld, lpr);
+    // LDS images of factor rows (hot rows of H^T, W tiles): the row in memory plus padding, or -- when the solver says
+    // how many columns hold data (k = 50 lives in rows of 64) -- only those: a quarter more rows in the same LDS
+    const int lds_ld_sw = ld + lds_pad_for(ld, lpr);   // the sweep's accumulator rows keep the memory layout
+    const int dcols = (int)round_up(data_cols, VEC);
+    const int lds_ld = (tune.lds_compact && data_cols > 0 && dcols < ld) ? dcols : lds_ld_sw;
     MNMF_TRY(ensure_prepared());
     if (&M == &Xt) {
       // document block = rows of W worth about one XCD's 4 MiB L2 (measured optimum at C2 / C3 / C4: 4 MiB against
@@ -908,7 +925,7 @@ class Engine : public ImplBase {
         if (ctx->n_ranks > 1) n_hot -= n_hot % ctx->n_ranks;
       }
       // rare words: synchronised sweep with LDS accumulators (one vector per lane only)
-      const size_t sweep_rb = (vmap() && tune.sweep > 0 && (vpl == 1 || lpr == 16) && !tune.force_wide) ? (size_t)lds_ld * sizeof(T) : 0;
+      const size_t sweep_rb = (vmap() && tune.sweep > 0 && (vpl == 1 || lpr == 16) && !tune.force_wide) ? (size_t)lds_ld_sw * sizeof(T) : 0;
       MNMF_TRY(ensure_xt(bs, n_hot, tile_rows, sweep_rb));
       if (xt_layout_only) return 0;   // agree_early_exchange: only the streams' layout is wanted
     }
@@ -919,7 +936,7 @@ class Engine : public ImplBase {
       MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 1));
       if (Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 1));
       if (Xt.nnz > 0) MNMF_TRY(spmm_stream(Xt, B, ld, out, lpr, vpl, ng, lds_ld, 2));
-      if (Xs.nnz > 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
+      if (Xs.nnz > 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld_sw, lpr, vpl));
       E_HIP(hipEventRecord(xt_cold_event, ctx->stream));
       if (Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       return 0;
@@ -937,7 +954,7 @@ class Engine : public ImplBase {
         E_HIP(hipEventRecord(ev_fork, ctx->stream));
         E_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
       }
-      if (tune.sweep_order == 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
+      if (tune.sweep_order == 0) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld_sw, lpr, vpl));
       if ((tune.sweep_order == 1 || tune.sweep_order == 3) && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       if (Xt.nnz > 0) {
         if (fork) st_override = side_stream;
@@ -948,12 +965,12 @@ class Engine : public ImplBase {
       if (tune.sweep_order != 1 && tune.sweep_order != 3 && Xth.nnz > 0) MNMF_TRY(spmm_stream(Xth, B, ld, out, lpr, vpl, ng, lds_ld, 2));
       // order 3: the sweep follows the tile stream on the caller's stream, before the join -- its workgroups take the CUs
       // as the tile kernel's drain, beside the tail of the blocked stream and the fix-up kernels of both streams
-      if (tune.sweep_order == 3) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
+      if (tune.sweep_order == 3) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld_sw, lpr, vpl));
       if (fork) {
         E_HIP(hipEventRecord(ev_join, side_stream));
         E_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
       }
-      if (tune.sweep_order != 0 && tune.sweep_order != 3) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld, lpr, vpl));
+      if (tune.sweep_order != 0 && tune.sweep_order != 3) MNMF_TRY(sweep_dispatch(B, ld, out, lds_ld_sw, lpr, vpl));
       return 0;
     }
     if (&M == &Xt && Xth.nnz > 0 && tune.xt_overlap) {
@@ -1686,6 +1703,7 @@ class Engine : public ImplBase {
   }
 
   int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
+    ColsGuard cols_guard(data_cols, k);
     MNMF_TRY(check_ready(k));
     const int ld = ld_of(k);
     const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 10000;
@@ -1927,6 +1945,7 @@ class Engine : public ImplBase {
         sum += ks[p];
       }
       MNMF_TRY(check_ready(sum));
+      ColsGuard cols_guard(data_cols, sum);
       const int ld = ld_of(sum);
       constexpr int kLine = (int)(128 / sizeof(T));   // factor columns in one 128-byte row: 32 floats / 16 doubles
       if (sum > kLine || ld != kLine || !can_fuse(ld))
@@ -2101,6 +2120,7 @@ class Engine : public ImplBase {
 
   // ------------------------------------------------------------------ loop B
   int run_pnmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
+    ColsGuard cols_guard(data_cols, k);
     MNMF_TRY(check_ready(k));
     const int ld = ld_of(k);
     const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 1000;
@@ -2241,6 +2261,7 @@ class Engine : public ImplBase {
 
   // ------------------------------------------------------------------ loop C
   int run_nmtf(int k, void* W, void* S, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
+    ColsGuard cols_guard(data_cols, k);
     MNMF_TRY(check_ready(k));
     const int ld = ld_of(k);
     const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 1000;
@@ -2466,6 +2487,7 @@ class Engine : public ImplBase {
   // ------------------------------------------------------------------ kernel-level entry points
   int k_spmm(int transpose, int k, const void* B, void* out) override {
     MNMF_TRY(check_ready(k));
+    ColsGuard cols_guard(data_cols, k);
     const int ld = ld_of(k);
     StreamMat<T>& M = transpose ? Xt : X;
     E_HIP(tmpA.ensure((size_t)std::max<int64_t>(M.tab_rows, 1) * ld * sizeof(T)));

@@ -74,6 +74,9 @@ struct SpmmArgs {
   int n_tiles;
   int tile_rows;
   int64_t tab_rows;          // rows of B
+  int kreal;                 // columns that hold data (<= nc; the rest of a padded row of B is zero).  The LDS images
+                             // (HOT, TILE) may be compact -- lds_ld = kreal rounded up to a vector, less than ld -- so
+                             // that more rows fit; the lanes beyond then read into the next row and store zeros
 };
 
 // SPMM_QUEUE: the PLAIN kernel as a persistent launch (a few 256-thread workgroups per CU): like HOT without the LDS
@@ -100,6 +103,42 @@ enum SpmmMode { SPMM_PLAIN = 0, SPMM_HOT = 1, SPMM_TILE = 2, SPMM_QUEUE = 3 };
 // whose gather indices are local to the tile -- every gather is an LDS read, the vector-memory path only carries
 // the nnz stream and the carry stores.  Profiling showed both SpMMs bound by the texture-addresser (TA busy
 // 80-93 %), which this takes out of the picture for about half of the nnz.
+// Copy `rows` consecutive rows of a factor (row stride ld elements, contiguous in memory) into an LDS image with row
+// stride lds_ld: padded (lds_ld >= ld, the whole row is copied) or compact (lds_ld < ld: only the first lds_ld
+// elements of a row, the ones that hold data).  SU 16-byte buffer loads are in flight per thread before the first
+// LDS write (one load at a time, each waited for, left a third of a tile's time to memory latency), on a descriptor of
+// exactly those rows: past their end a load returns zeros, which are not stored.
+template <typename T, int SU>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ src, int rows, int ld, int lds_ld, T* __restrict__ lds) {
+  using U4 = __attribute__((ext_vector_type(4))) unsigned int;
+  constexpr int VEC = VecOf<T>::N;
+  const int nvr = ld / VEC;                               // vectors per row in memory
+  const int nvc = (lds_ld < ld ? lds_ld : ld) / VEC;      // ... of them copied
+  const int nvl = lds_ld / VEC;                           // ... per row of the image
+  const int total = rows * nvc;
+  const bool same = lds_ld == ld;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src), 0, (uint32_t)(rows * nvr) * 16u, 0x00020000);
+  for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * SU) {
+    U4 t[SU];
+    uint32_t o[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      uint32_t g = (uint32_t)i;
+      o[u] = (uint32_t)i * 16u;
+      if (!same) {
+        const int r = i / nvc, c = i - r * nvc;
+        g = (uint32_t)(r * nvr + c);
+        o[u] = (uint32_t)(r * nvl + c) * 16u;
+      }
+      t[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, i < total ? g * 16u : 0xfffffff0u, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+      if (i0 + u * (int)blockDim.x < total) *reinterpret_cast<U4*>(reinterpret_cast<char*>(lds) + o[u]) = t[u];
+  }
+}
+
 template <typename T, int LPR, int VPL, int DIR, int MODE, bool WIDE>
 __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
   constexpr bool HOT = MODE == SPMM_HOT;
@@ -121,28 +160,7 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
   if (HOT) {
     // the hot rows are the first rows of B, contiguous in memory: SU loads in flight per thread before the first LDS
     // write, on a descriptor of exactly those rows (past their end a load returns zeros, which are not stored)
-    constexpr int SU = 6;
-    const int nvr = ld / VEC;
-    const int total = a.hot_rows * nvr;
-    const bool same = a.lds_ld == ld;
-    __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.B), 0, (uint32_t)total * 16u, 0x00020000);
-    for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * SU) {
-      U4 t[SU];
-#pragma unroll
-      for (int u = 0; u < SU; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (uint32_t)(i0 + u * (int)blockDim.x) * 16u, 0, 0);
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int i = i0 + u * (int)blockDim.x;
-        if (i < total) {
-          uint32_t o = (uint32_t)i * 16u;
-          if (!same) {
-            const int r = i / nvr;
-            o = ((uint32_t)r * (uint32_t)a.lds_ld + (uint32_t)(i - r * nvr) * VEC) * (uint32_t)sizeof(T);
-          }
-          *reinterpret_cast<U4*>(reinterpret_cast<char*>(lds) + o) = t[u];
-        }
-      }
-    }
+    stage_rows<T, 6>(a.B, a.hot_rows, ld, a.lds_ld, lds);
     __syncthreads();
   }
 #if MNMF_ABLATE == 5 || MNMF_ABLATE == 7   // the unstaged tile must at least hold finite numbers
@@ -154,7 +172,7 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
   const int lane = threadIdx.x & 63;
   const int gi = lane / LPR, li = lane % LPR;
   const int gbase = gi * LPR;
-  bool colok[VPL];
+  bool colok[VPL], colreal[VPL];
   uint32_t cbytes[VPL];  // byte offset of this lane's vector in a row (clamped to 0 for lanes beyond the columns)
   uint32_t lbytes[VPL];  // the same for LDS reads, NOT clamped: idle lanes that all read offset 0 of their row put a
                          // second address on banks other lanes of the same ds_read_b128 lane group use (6 LDS cycles
@@ -164,6 +182,7 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
   for (int w = 0; w < VPL; ++w) {
     const int coff = (w * LPR + li) * VEC;
     colok[w] = coff < a.nc;
+    colreal[w] = coff < a.kreal;
     cbytes[w] = colok[w] ? (uint32_t)coff * (uint32_t)sizeof(T) : 0u;
     lbytes[w] = (uint32_t)coff * (uint32_t)sizeof(T);
   }
@@ -177,34 +196,13 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
     __syncthreads();  // every wave is done with the previous tile
     const int64_t r0 = tile * a.tile_rows;
     const int nrow = (int)((a.tab_rows - r0 < a.tile_rows) ? a.tab_rows - r0 : a.tile_rows);
-    const int nvr = ld / VEC;
     const T* src = a.B + r0 * ld;
 #if MNMF_ABLATE != 5 && MNMF_ABLATE != 7   // 5, 7: timing experiment only, the tile is not staged
     {
       // the tile is contiguous in memory (nrow rows of ld elements); SU loads are in flight per thread before the first
       // LDS write (one load at a time, each waited for, left a third of the tile's time to memory latency).  Buffer
       // loads on a descriptor of the tile itself: past its end they return zeros, which are not stored.
-      constexpr int SU = 6;
-      const int total = nrow * nvr;
-      const bool same = a.lds_ld == ld;
-      __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src), 0, (uint32_t)total * 16u, 0x00020000);
-      for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * SU) {
-        U4 t[SU];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(trs, (uint32_t)(i0 + u * (int)blockDim.x) * 16u, 0, 0);
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int i = i0 + u * (int)blockDim.x;
-          if (i < total) {
-            uint32_t o = (uint32_t)i * 16u;
-            if (!same) {
-              const int r = i / nvr;
-              o = ((uint32_t)r * (uint32_t)a.lds_ld + (uint32_t)(i - r * nvr) * VEC) * (uint32_t)sizeof(T);
-            }
-            *reinterpret_cast<U4*>(reinterpret_cast<char*>(lds) + o) = t[u];
-          }
-        }
-      }
+      stage_rows<T, 6>(src, nrow, ld, a.lds_ld, lds);
     }
 #endif
     __syncthreads();
@@ -437,7 +435,7 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
 #endif
                   VT o;
 #pragma unroll
-                  for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
+                  for (int x = 0; x < VEC; ++x) o.v[x] = colreal[w] ? acc[w][x] : T(0);
 #if MNMF_NT_STORE   // experiment: output rows and carries are written once and read by another kernel
                   U4 ou;
                   __builtin_memcpy(&ou, &o, sizeof(VT));

@@ -203,6 +203,27 @@ def test_solver_on_lds_hot_path(hot_engines, golden):
     assert rel(host(W), g["nmf_W_20"]) <= 1e-10 and rel(host(H), g["nmf_H_20"]) <= 1e-10
 
 
+@pytest.mark.parametrize("dtype,k", [("fp64", 50), ("fp32", 50), ("fp32", 37)])
+def test_solver_on_compact_lds_rows(hot_engines, golden, dtype, k):
+    """k = 50 lives in factor rows of 64 elements: the LDS images of the hot H^T rows and of the W tiles hold only the
+    columns with data (compact rows), the lanes beyond read into the next row and must store zeros -- garbage in the
+    padding of a numerator would reach the next iteration through the update kernels.  20 iterations against the CPU
+    oracle."""
+    from oracle import nmf_oracle as oc
+
+    g = golden("fixed_B_1000x1200_k10")
+    X = g["X"]
+    rng = np.random.RandomState(k)
+    W0, H0 = rng.uniform(0, X.max(), (X.shape[0], k)), rng.uniform(0, X.max(), (k, X.shape[1]))
+    want = oc.basic_nmf(X, W0.copy(), H0.copy(), zero_threshold=1e-5, n_iter=20, check=False)
+    eng = hot_engines[dtype]
+    eng.set_matrix(X)
+    W, H, _ = eng.run_nmf(W0, H0, fixed_iters=20, zero_threshold=1e-5)
+    tol = 1e-10 if dtype == "fp64" else 2e-4
+    assert rel(host(W), want["W"]) <= tol and rel(host(H), want["H"]) <= tol
+    assert rel(host(eng.spmm(H0.T)), X @ H0.T) <= TOL[dtype]
+
+
 @pytest.fixture(scope="module")
 def small_segment_engines():
     """Engines with 8-nnz segments: every long row is cut into many segments, so its carry list is long enough
