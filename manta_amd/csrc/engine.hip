@@ -113,6 +113,8 @@ struct Tune {
                                       // configs[1] shard sizes of 1 / 4 / 8 ranks: 363 -> 324, 1101 -> 996, 1765 -> 1608 it/s)
   int early_check = 0;                // tests: fail instead of falling back when the early exchange cannot be taken
   int async_gram = 1;                 // sharded NMF: the k x k all-reduce of an iteration's end on a stream of its own, beside the next X^T.W
+  int hot_wgs_per_cu = 1;             // X.H^T LDS-hot kernel: workgroups per CU (each with its share of hot_lds_bytes) ...
+  int hot_threads = 1024;             // ... of this many threads
   int lds_compact = 1;                // LDS images of factor rows hold only the columns with data (spmm())
   int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
@@ -153,6 +155,8 @@ struct Tune {
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
     lds_compact = (int)geti("MNMF_LDS_COMPACT", lds_compact);
+    hot_wgs_per_cu = (int)geti("MNMF_HOT_WGS", hot_wgs_per_cu);
+    hot_threads = (int)geti("MNMF_HOT_THREADS", hot_threads);
     async_gram = (int)geti("MNMF_ASYNC_GRAM", async_gram);
     early_exchange = (int)geti("MNMF_EARLY_EXCHANGE", early_exchange);
     early_check = (int)geti("MNMF_EARLY_CHECK", early_check);
@@ -810,7 +814,8 @@ class Engine : public ImplBase {
       auto kern = spmm_stream_kernel<T, LPR, VPL, 0, SPMM_HOT, false>;
       const size_t lds_bytes = (size_t)hot * lds_ld * sizeof(T) + kLdsSlack;
       E_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      kern<<<(unsigned)n_cus, 1024, lds_bytes, st()>>>(a);
+      const int wgs = std::max(1, tune.hot_wgs_per_cu);
+      kern<<<(unsigned)(n_cus * wgs), std::min(tune.hot_threads, 1024), lds_bytes, st()>>>(a);
       E_LAUNCH();
     } else if (waves > 0 && !wide && tune.queue && (&M == &Xt || tune.queue >= 2)) {
       // persistent PLAIN: lane groups walk their segment queues back to back (spmm.hpp, SPMM_QUEUE).  The grid is what
@@ -1089,7 +1094,7 @@ class Engine : public ImplBase {
     int hot = 0;
     if (&M == &X && vmap() && tune.hot_lds_bytes > 0 && M.nnz >= hot_x_threshold(lpr) &&
         (int64_t)M.tab_rows * ld * (int64_t)sizeof(T) < ((int64_t)1 << 31)) {
-      hot = (int)std::min<int64_t>(M.tab_rows, tune.hot_lds_bytes / ((int64_t)lds_ld * (int64_t)sizeof(T)));
+      hot = (int)std::min<int64_t>(M.tab_rows, tune.hot_lds_bytes / std::max(1, tune.hot_wgs_per_cu) / ((int64_t)lds_ld * (int64_t)sizeof(T)));
       if (hot < 16) hot = 0;
     }
     return spmm_dispatch(M, B, ld, ld, 0, out, hot, lds_ld, vpl, lpr);

@@ -37,6 +37,9 @@
 #ifndef MNMF_HOT_EPL
 #define MNMF_HOT_EPL 1    // chunk length of the HOT / PLAIN modes in units of max(16, LPR) nnz
 #endif
+#ifndef MNMF_HOT_U
+#define MNMF_HOT_U 8      // gathers per batch in the HOT mode (one vector per lane)
+#endif
 #ifndef MNMF_PLAIN_EPL
 #define MNMF_PLAIN_EPL 1
 #endif
@@ -140,7 +143,11 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ src, int rows, 
 }
 
 template <typename T, int LPR, int VPL, int DIR, int MODE, bool WIDE>
-__global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 256) void spmm_stream_kernel(const SpmmArgs<T> a) {
+#ifndef MNMF_HOT_BLOCK
+#define MNMF_HOT_BLOCK 1024
+#define MNMF_HOT_WAVES 4
+#endif
+__global__ __launch_bounds__(MODE == SPMM_HOT ? MNMF_HOT_BLOCK : MODE == SPMM_TILE ? 1024 : 256, MODE == SPMM_HOT ? MNMF_HOT_WAVES : 1) void spmm_stream_kernel(const SpmmArgs<T> a) {
   constexpr bool HOT = MODE == SPMM_HOT;
   constexpr bool TILE = MODE == SPMM_TILE;
   constexpr int VEC = VecOf<T>::N;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__((MODE == SPMM_HOT || MODE == SPMM_TILE) ? 1024 : 25
   constexpr int CH = (MODE == SPMM_TILE) ? LPR * (MNMF_TILE_CH / LPR > 8 ? 8 : (MNMF_TILE_CH / LPR < 1 ? 1 : MNMF_TILE_CH / LPR))
                                          : (LPR < 16 ? 16 : LPR) * (MODE == SPMM_HOT ? MNMF_HOT_EPL : MNMF_PLAIN_EPL);
   constexpr int EPL = CH / LPR;            // chunk elements held per lane
-  constexpr int U = VPL == 2 ? 4 : 8;      // gathers in flight per batch
+  constexpr int U = VPL == 2 ? 4 : (MODE == SPMM_HOT ? MNMF_HOT_U : 8);   // gathers in flight per batch
   static_assert(CH % U == 0, "U must divide CH");
   extern __shared__ __align__(16) unsigned char mnmf_smem[];
   T* lds = reinterpret_cast<T*>(mnmf_smem);
