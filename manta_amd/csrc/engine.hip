@@ -55,8 +55,13 @@ struct DevBuf {
 // sets Engine::data_cols for the duration of a solver call
 struct ColsGuard {
   int& ref;
+  bool* line = nullptr;
   ColsGuard(int& r, int k) : ref(r) { ref = k; }
-  ~ColsGuard() { ref = 0; }
+  ColsGuard(int& r, int k, bool& line_layout, bool on) : ref(r), line(&line_layout) { ref = k; line_layout = on; }
+  ~ColsGuard() {
+    ref = 0;
+    if (line) *line = false;
+  }
   ColsGuard(const ColsGuard&) = delete;
   ColsGuard& operator=(const ColsGuard&) = delete;
 };
@@ -286,6 +291,8 @@ class Engine : public ImplBase {
   hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
   hipEvent_t ev_cold = nullptr, ev_hot = nullptr, ev_h_done = nullptr;   // early exchange of a sharded NMF iteration
   int data_cols = 0;                    // columns of the factors that hold data in the running solver call (0: all ld), ColsGuard
+  bool line_layout = false;             // run_nmf / run_nmf_sweep with one 128-byte line per factor row: the layout of X^T must
+                                        // not depend on k (spmm())
   bool xt_layout_only = false;          // spmm(Xt, ...) stops after the streams are laid out
   hipEvent_t xt_cold_event = nullptr;   // set around spmm(Xt, ...): cold streams first, this event, then the tile stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -901,7 +908,12 @@ class Engine : public ImplBase {
     // how many columns hold data (k = 50 lives in rows of 64) -- only those: a quarter more rows in the same LDS
     const int lds_ld_sw = ld + lds_pad_for(ld, lpr);   // the sweep's accumulator rows keep the memory layout
     const int dcols = (int)round_up(data_cols, VEC);
-    const int lds_ld = (tune.lds_compact && data_cols > 0 && dcols < ld) ? dcols : lds_ld_sw;
+    // Not for the tile stream of standard NMF with one 128-byte line per row (k <= 32 floats / 16 doubles): the tiles,
+    // and with them the order in which a word's partial sums are added, would depend on k, and a problem in a batched
+    // topic-count sweep (run_nmf_sweep, all of them side by side in the line) must see exactly the sums of its own
+    // run_nmf.  Which rows of H^T come from LDS in X.H^T changes no sum.  (MNMF_LDS_COMPACT=2: compact there too.)
+    const bool compact = tune.lds_compact && data_cols > 0 && dcols < ld && !(&M == &Xt && line_layout && tune.lds_compact < 2);
+    const int lds_ld = compact ? dcols : lds_ld_sw;
     MNMF_TRY(ensure_prepared());
     if (&M == &Xt) {
       // document block = rows of W worth about one XCD's 4 MiB L2 (measured optimum at C2 / C3 / C4: 4 MiB against
@@ -1708,7 +1720,7 @@ class Engine : public ImplBase {
   }
 
   int run_nmf(int k, void* W, void* H, const mnmf_opts* o, mnmf_stats* stats) override {
-    ColsGuard cols_guard(data_cols, k);
+    ColsGuard cols_guard(data_cols, k, line_layout, k > 0 && (size_t)ld_of(k) * sizeof(T) == 128);
     MNMF_TRY(check_ready(k));
     const int ld = ld_of(k);
     const int64_t max_iter = (o && o->max_iter >= 0) ? o->max_iter : 10000;
@@ -1950,7 +1962,7 @@ class Engine : public ImplBase {
         sum += ks[p];
       }
       MNMF_TRY(check_ready(sum));
-      ColsGuard cols_guard(data_cols, sum);
+      ColsGuard cols_guard(data_cols, sum, line_layout, true);
       const int ld = ld_of(sum);
       constexpr int kLine = (int)(128 / sizeof(T));   // factor columns in one 128-byte row: 32 floats / 16 doubles
       if (sum > kLine || ld != kLine || !can_fuse(ld))

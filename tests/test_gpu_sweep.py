@@ -180,3 +180,28 @@ def test_run_nmf_sweep_default_dtype_batches(golden):
     for k, (W0, H0), out in zip(ks, st, got):
         want = manta_amd.run_nmf(k, X, norm_thresh=0.005, W0=W0, H0=H0)
         assert np.array_equal(out["W"], want["W"]) and np.array_equal(out["H"], want["H"])
+
+
+def test_sweep_bit_identical_on_the_lds_paths(golden, monkeypatch):
+    """The same claim with the LDS-staged SpMM paths forced on (hot rows of H^T, W tiles: normally only for large
+    matrices): the tiles of X^T.W -- and with them the order of a word's partial sums -- must not depend on the number
+    of columns in use, or a problem of the batch (30 columns side by side) would differ from its own run (5, 10, 15)."""
+    from manta_amd.engine import Engine
+
+    for k_, v in dict(MNMF_HOT_MIN_NNZ="0", MNMF_HOT_LDS_BYTES="20000", MNMF_TILE_LDS_BYTES="40000", MNMF_XT_HOT_WORDS="40",
+                      MNMF_TILE_MIN_ROWS="64", MNMF_TILE_MIN_TILES_PCT="0").items():
+        monkeypatch.setenv(k_, v)
+    for dtype, ks in (("fp32", (5, 10, 15)), ("fp64", (3, 6, 5))):
+        e = Engine(dtype=dtype)
+        try:
+            g = golden("fixed_B_1000x1200_k10")
+            X = g["X"]
+            e.set_matrix(X)
+            st = starts_for(X, ks, 11)
+            got = e.run_nmf_sweep([a for a, _ in st], [b for _, b in st], fixed_iters=15, force_check=True, zero_threshold=1e-5)
+            for (W0, H0), (W, H, s) in zip(st, got):
+                W1, H1, s1 = e.run_nmf(W0, H0, fixed_iters=15, force_check=True, zero_threshold=1e-5)
+                assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
+                assert s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
+        finally:
+            e.close()
