@@ -1,4 +1,4 @@
-"""Launcher of the multi-process tests (tests/test_dist.py, tests/test_zy_dist_gpu.py)."""
+"""Launcher of the multi-process tests (tests/test_dist.py, tests/test_00_dist_gpu.py)."""
 import os
 import subprocess
 import sys
@@ -37,7 +37,7 @@ def run_with_heartbeat(cmd, env, timeout=300):
 
 def launch(args, port, nproc=2, stall_ok=False, **extra_env):
     """stall_ok: a run that is still going after the time limit is a SKIP, not a failure -- only for the cases that put
-    several ranks with three HIP streams each on one GPU (see tests/test_zy_dist_gpu.py)."""
+    several ranks with three HIP streams each on one GPU (see tests/test_00_dist_gpu.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER] + args

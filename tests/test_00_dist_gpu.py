@@ -1,7 +1,8 @@
 """The document-sharded path on the GPU: several ranks sharing the one GPU of the test box (exchange over gloo) and the
-RCCL branch in a group of one.  Collected late on purpose (the file name): ranks that share a GPU can stall for minutes
-when their queues are time-sliced, and `pytest -x` must not hide the single-process parity tests behind such a stall.
-Only tests/test_zz_no_alloc.py comes after."""
+RCCL branch in a group of one.  Collected FIRST on purpose (the file name): the ranks are child processes, and they
+share the GPU best while the pytest process itself has not touched it yet -- run after the single-process GPU tests
+(the parent then holds a context, streams and queues of its own) the same launches took 60-180 s instead of 3-30 and
+the two early-exchange cases did not finish in their time limit."""
 import os
 import subprocess
 import sys
