@@ -121,7 +121,7 @@ struct Tune {
   int hot_wgs_per_cu = 1;             // X.H^T LDS-hot kernel: workgroups per CU (each with its share of hot_lds_bytes) ...
   int hot_threads = 1024;             // ... of this many threads
   int lds_compact = 1;                // LDS images of factor rows hold only the columns with data (spmm())
-  int two_vec = 1;                    // fp64 rows of 17..32 vectors: 16 lanes x 2 vectors per row instead of 32 x 1
+  int two_vec = 1;                    // rows of 17..32 vectors (fp64 k = 33..64, fp32 k = 65..128): 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
     auto geti = [](const char* n, int64_t d) { const char* v = std::getenv(n); return v ? (int64_t)std::atoll(v) : d; };
     x_q = geti("MNMF_X_Q", x_q);
@@ -899,10 +899,15 @@ class Engine : public ImplBase {
     const int nvec = ld / VEC;
     int vpl = nvec > 64 ? 2 : 1;
     int lpr = vpl == 2 ? 64 : std::max(4, pow2_ceil(nvec));
-    // fp64 rows of 17..32 vectors (k = 33..64: 272..512 bytes): 16 lanes x 2 vectors per row instead of 32 x 1 -- four
-    // rows per wave-level gather as fp32 has, half the steps per nnz, and the 16-lane LDS paths (hot rows of H^T, W
-    // tiles) that never paid at 32 lanes (hot_x_threshold)
-    if (tune.two_vec && sizeof(T) == 8 && lpr == 32) lpr = 16, vpl = 2;
+    // rows of 17..32 vectors (272..512 bytes: fp64 k = 33..64, fp32 k = 65..128): 16 lanes x 2 vectors per row instead
+    // of 32 x 1 -- four rows per wave-level gather as the narrower rows have, half the steps per nnz, and the 16-lane
+    // LDS paths (hot rows of H^T, W tiles) that never paid at 32 lanes (hot_x_threshold).  configs[1] in fp64 155 -> 161
+    // it/s, configs[2] (k = 100, fp32) 153 -> 161
+    // (the same one step up -- 33..64 vectors on 32 lanes x 2 instead of 64 x 1 -- lost: configs[4] shard 27.63 -> 27.03
+    // it/s, configs[2] in fp64 84.4 -> 79.8)
+    // ... and one step down -- 9..16 vectors on 8 lanes x 2 instead of 16 x 1 -- too: configs[1] X.H^T 1.14 -> 1.38 ms,
+    // X^T.W 1.18 -> 1.26.  Sixteen lanes per row it is.
+    if (tune.two_vec && lpr == 32) lpr = 16, vpl = 2;
     const int ng = kWave / lpr;
     // LDS images of factor rows (hot rows of H^T, W tiles): the row in memory plus padding, or -- when the solver says
     // how many columns hold data (k = 50 lives in rows of 64) -- only those: a quarter more rows in the same LDS
@@ -1135,8 +1140,8 @@ class Engine : public ImplBase {
   }
   int sweep_dispatch(const T* B, int ld, T* out, int lds_ld, int lpr, int vpl = 1) {
     if (vpl == 2) {
-      if constexpr (sizeof(T) == 8) return sweep_launch<16, 2>(B, ld, out, lds_ld);
-      return fail(MNMF_ESTATE, "sweep: two vectors per lane only for 16-lane fp64 rows");
+      if (lpr == 16) return sweep_launch<16, 2>(B, ld, out, lds_ld);
+      return fail(MNMF_ESTATE, "sweep: two vectors per lane only for rows on 16 lanes");
     }
     switch (lpr) {
       case 4: return sweep_launch<4>(B, ld, out, lds_ld);
@@ -1148,9 +1153,7 @@ class Engine : public ImplBase {
   }
 
   int spmm_dispatch(StreamMat<T>& M, const T* B, int ld, int nc, int c0, T* out, int hot, int lds_ld, int vpl, int lpr) {
-    if (vpl == 2 && lpr == 16) {
-      if constexpr (sizeof(T) == 8) return spmm_launch<16, 2>(M, B, ld, nc, c0, out, hot, lds_ld);
-    }
+    if (vpl == 2 && lpr == 16) return spmm_launch<16, 2>(M, B, ld, nc, c0, out, hot, lds_ld);
     if (vpl == 2) return spmm_launch<64, 2>(M, B, ld, nc, c0, out, hot, lds_ld);
     switch (lpr) {
       case 4: return spmm_launch<4, 1>(M, B, ld, nc, c0, out, hot, lds_ld);
