@@ -1,5 +1,6 @@
 """Launcher of the multi-process tests (tests/test_dist.py, tests/test_00_dist_gpu.py)."""
 import os
+import signal
 import subprocess
 import sys
 import time
@@ -16,7 +17,7 @@ def run_with_heartbeat(cmd, env, timeout=300):
 
     beat = os.path.join(ROOT, "gpurun_out", ".heartbeat") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
     with tempfile.TemporaryFile("w+") as out, tempfile.TemporaryFile("w+") as err:
-        p = subprocess.Popen(cmd, env=env, stdout=out, stderr=err, text=True)
+        p = subprocess.Popen(cmd, env=env, stdout=out, stderr=err, text=True, start_new_session=True)
         t0 = time.time()
         while True:
             try:
@@ -27,7 +28,10 @@ def run_with_heartbeat(cmd, env, timeout=300):
                     with open(beat, "a") as f:
                         f.write("%s %.0f s\n" % (os.path.basename(cmd[-1]) if cmd else "", time.time() - t0))
                 if time.time() - t0 > timeout:
-                    p.kill()
+                    try:   # the launcher and its ranks: a process group of their own (start_new_session)
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
                     p.wait()
                     break
         out.seek(0)
