@@ -13,6 +13,13 @@
 #include "common.hpp"
 #include "dense.hpp"
 
+#ifndef MNMF_RK_FAST_DIV
+#define MNMF_RK_FAST_DIV 0
+#endif
+#ifndef MNMF_RK_PREFETCH
+#define MNMF_RK_PREFETCH 1   // dense_rk_mfma_f32_kernel: epilogue operands fetched one group ahead (0: in front of their group)
+#endif
+
 namespace mnmf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -355,6 +362,31 @@ void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restric
     for (int q = 0; q < NT; ++q)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    // The epilogue works in groups of EG accumulator rows.  Numerator and old factor of a group are fetched one group
+    // ahead -- the first group's before the products below, the next group's before this group's stores (the compiler
+    // cannot prove that `out` does not alias them and never moves a load above a store) -- so their trip to memory
+    // runs behind MFMAs instead of in front of them (the matrix cores idled half of the kernel).
+    constexpr int EG = NT <= 2 ? 8 : 4;
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.num + (MODE != RK_PROD ? tbase : 0)), 0, tbytes, kFlags);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.upd + (MODE != RK_PROD ? tbase : 0)), 0, tbytes, kFlags);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + tbase, 0, tbytes, kFlags);
+    float nv[2][NT][EG], uv[2][NT][EG];
+    auto load_group = [&](auto bufc, int e0) {
+      constexpr int buf = decltype(bufc)::value;
+      if (MODE != RK_PROD) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+          for (int x = 0; x < EG; ++x) {
+            const int e = e0 + x;
+            const unsigned off = eoff[q] + (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;
+            nv[buf][q][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, off, 0, 0));
+            uv[buf][q][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, off, 0, 0));
+          }
+      }
+    };
+    constexpr bool PF = MNMF_RK_PREFETCH && NT <= 4;   // wider tiles have no registers to spare
+    if (PF) load_group(std::integral_constant<int, 0>{}, 0);
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {
       const float* A = pair == 0 ? a.A1 : a.A2;
@@ -402,26 +434,14 @@ void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restric
                                                           acc[q], 0, 0, 0);
       }
     }
-    // epilogue in groups of EG accumulator rows: a group's loads are all issued before its first store; with FUSE
-    // the group's new values and differences go straight into the Gram MFMAs.
-    constexpr int EG = NT <= 2 ? 8 : 4;
-    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.num + (MODE != RK_PROD ? tbase : 0)), 0, tbytes, kFlags);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.upd + (MODE != RK_PROD ? tbase : 0)), 0, tbytes, kFlags);
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + tbase, 0, tbytes, kFlags);
-#pragma unroll
-    for (int e0 = 0; e0 < 16; e0 += EG) {
-      float nv[NT][EG], uv[NT][EG];
-      if (MODE != RK_PROD) {
-#pragma unroll
-        for (int q = 0; q < NT; ++q)
-#pragma unroll
-          for (int x = 0; x < EG; ++x) {
-            const int e = e0 + x;
-            const unsigned off = eoff[q] + (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;
-            nv[q][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, off, 0, 0));
-            uv[q][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, off, 0, 0));
-          }
-      }
+    // epilogue in groups of EG accumulator rows: a group's loads are all issued before the previous group's first
+    // store; with FUSE the group's new values and differences go straight into the Gram MFMAs.
+    static_for<16 / EG>([&](auto gc_) {
+      constexpr int grp = decltype(gc_)::value;
+      constexpr int e0 = grp * EG;
+      constexpr int cur = PF ? (grp & 1) : 0;
+      if (!PF) load_group(std::integral_constant<int, 0>{}, e0);
+      else if (grp + 1 < 16 / EG) load_group(std::integral_constant<int, 1 - cur>{}, e0 + EG);
       float on[NT][EG], od[NT][EG];
 #pragma unroll
       for (int q = 0; q < NT; ++q)
@@ -432,14 +452,18 @@ void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restric
           const unsigned off = eoff[q] + (unsigned)((e & 3) + 8 * (e >> 2)) * rowb;
           float o = acc[q][e];
           if (MODE != RK_PROD) {
-            const float qn = nv[q][x] / (o + a.eps);
-            o = uv[q][x] * (MODE == RK_MU_SQRT ? sqrtf(qn) : qn);
+#if MNMF_RK_FAST_DIV   // timing experiment: 1-ulp reciprocal instead of the correctly rounded quotient
+            const float qn = nv[cur][q][x] * __builtin_amdgcn_rcpf(o + a.eps);
+#else
+            const float qn = nv[cur][q][x] / (o + a.eps);
+#endif
+            o = uv[cur][q][x] * (MODE == RK_MU_SQRT ? sqrtf(qn) : qn);
           }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, off, 0, 0);   // dropped when out of the tile
           if (FUSE) {
             const bool ok = cok[q] && r < rleft;
             on[q][x] = ok ? o : 0.f;
-            od[q][x] = ok ? fabsf(o - uv[q][x]) : 0.f;
+            od[q][x] = ok ? fabsf(o - uv[cur][q][x]) : 0.f;
           }
         }
       if (FUSE) {
@@ -455,7 +479,7 @@ void dense_rk_mfma_f32_kernel(RkArgs<float> a, int64_t n_tiles, float* __restric
             }
         }
       }
-    }
+    });
   }
   if (FUSE) {
 #pragma unroll
