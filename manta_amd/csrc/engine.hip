@@ -120,6 +120,8 @@ struct Tune {
   int async_gram = 1;                 // sharded NMF: the k x k all-reduce of an iteration's end on a stream of its own, beside the next X^T.W
   int hot_wgs_per_cu = 1;             // X.H^T LDS-hot kernel: workgroups per CU (each with its share of hot_lds_bytes) ...
   int hot_threads = 1024;             // ... of this many threads
+  int fix_merge = 1;                  // small streams: one fix-up launch for long rows, short rows and rows without nnz
+  int64_t fix_merge_bytes = 16 << 20; // ... up to this many bytes of carry slots (at 128 bytes a slot)
   int lds_compact = 1;                // LDS images of factor rows hold only the columns with data (spmm())
   int two_vec = 1;                    // rows of 17..32 vectors (fp64 k = 33..64, fp32 k = 65..128): 16 lanes x 2 vectors per row instead of 32 x 1
   Tune() {
@@ -160,6 +162,8 @@ struct Tune {
     force_wide = (int)geti("MNMF_FORCE_WIDE", force_wide);
     two_vec = (int)geti("MNMF_TWO_VEC", two_vec);
     lds_compact = (int)geti("MNMF_LDS_COMPACT", lds_compact);
+    fix_merge = (int)geti("MNMF_FIX_MERGE", fix_merge);
+    fix_merge_bytes = geti("MNMF_FIX_MERGE_BYTES", fix_merge_bytes);
     hot_wgs_per_cu = (int)geti("MNMF_HOT_WGS", hot_wgs_per_cu);
     hot_threads = (int)geti("MNMF_HOT_THREADS", hot_threads);
     async_gram = (int)geti("MNMF_ASYNC_GRAM", async_gram);
@@ -223,6 +227,7 @@ struct StreamMat {
   DevBuf tile_first;                         // [n_tiles + 1] first segment of each tile
   // segment description for the current seg_q
   int64_t seg_q = -1, n_seg = 0, n_dest = 0, n_empty = 0, n_fix = 0, n_fix_long = 0, n_carry = 0;
+  bool fix_merged = false;   // one fix-up launch for everything, rows without nnz included (ensure_segments)
   int seg_group = -1;
   DevBuf seg_desc, dest, empty_rows, fix_row, fix_first, fix_count, carry;
 };
@@ -766,6 +771,24 @@ class Engine : public ImplBase {
       s.fix_first.swap(f);
       s.fix_count.swap(c);
     }
+    // Small streams that are alone on their output (X; X^T without a tile or sweep stream beside it): one fix-up launch
+    // for everything, and the rows without nnz join it as rows with no carry slots instead of a zeroing launch of their
+    // own in front of the stream kernel.
+    {
+      const bool alone = &M == &X || (&M == &Xt && Xth.nnz == 0 && Xs.nnz == 0);
+      const int64_t fix_bytes = (M.n_carry + M.n_empty) * (int64_t)128;
+      M.fix_merged = tune.fix_merge && alone && !tiled && fix_bytes <= tune.fix_merge_bytes && M.n_fix_long <= 4096;
+      if (M.fix_merged) {
+        for (int32_t r : s.empty_rows) {
+          s.fix_row.push_back(r);
+          s.fix_first.push_back(0);
+          s.fix_count.push_back(0);
+        }
+        s.empty_rows.clear();
+        M.n_empty = 0;
+        M.n_fix = (int64_t)s.fix_row.size();
+      }
+    }
     {  // one 16-byte descriptor per segment: a lane group fetches it with a single load
       std::vector<SegDesc> sd((size_t)s.n_seg());
       for (size_t i = 0; i < sd.size(); ++i) sd[i] = SegDesc{s.seg_start[i], s.seg_len[i], s.seg_info[i]};
@@ -858,6 +881,17 @@ class Engine : public ImplBase {
     const int32_t* fr = M.fix_row.template as<int32_t>();
     const int32_t* ff = M.fix_first.template as<int32_t>();
     const int32_t* fc = M.fix_count.template as<int32_t>();
+    // small streams: long rows, short rows and the rows without nnz (ensure_segments) in ONE launch -- at configs[0] a
+    // launch costs as much as the work it starts
+    if (M.fix_merged) {
+      if (M.n_fix > 0) {
+        const int64_t n_short = M.n_fix - M.n_fix_long;
+        spmm_fixup_both_kernel<T, LPR, VPL><<<(unsigned)(M.n_fix_long + cdiv(n_short, 4)), 256, 0, st()>>>(
+            fr, ff, fc, (int)M.n_fix_long, M.n_fix, carry, ld, nc, out);
+        E_LAUNCH();
+      }
+      return 0;
+    }
     if (M.n_fix_long > 0) {
       // few rows with very long lists (tile stream): 16 waves per row; many rows with moderate lists: 4
       if (M.n_fix_long <= (int64_t)8 * n_cus)
@@ -932,6 +966,15 @@ class Engine : public ImplBase {
       int n_hot = 0, tile_rows = 0;
       if (vmap() && tune.xt_hot_words != 0 && nnz >= tune.hot_min_nnz) {
         tile_rows = (int)std::min<int64_t>(tune.tile_lds_bytes / tune.tile_wgs_per_cu / ((int64_t)lds_ld * (int64_t)sizeof(T)), 1 << 15);
+        if (lds_ld < lds_ld_sw) {
+          // compact rows make room for more documents per tile, but not at the price of the tiles that keep the CUs busy
+          // (100k x 50k, k = 20, fp64: 950-document tiles are 105 tiles, under the minimum below -- the tile stream was
+          // dropped and X^T.W went 0.208 -> 0.287 ms; NMTF 200k x 50k with 155 tiles of 1298 documents instead of 165 of
+          // 1218: X^T.W 0.118 -> 0.123): as many documents as fit while there are two tiles per CU, never fewer than the
+          // padded layout holds -- the large matrices gain (configs[3] +5 %), the others keep their tiles
+          const int64_t padded = std::min<int64_t>(tune.tile_lds_bytes / tune.tile_wgs_per_cu / ((int64_t)lds_ld_sw * (int64_t)sizeof(T)), 1 << 15);
+          tile_rows = (int)std::max<int64_t>(padded, std::min<int64_t>(tile_rows, m / (2 * (int64_t)n_cus)));
+        }
         // every (tile, hot word) pair is a carry row: with wide rows (few documents per tile, many tiles) half as many
         // hot words cost less in carries than they lose in LDS gathers (832-byte rows: X^T.W 17.4 -> 15.8 ms at the
         // configs[4] shard; 448-512-byte rows: equal)

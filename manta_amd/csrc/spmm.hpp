@@ -621,6 +621,74 @@ __global__ __launch_bounds__(64 * NW) void spmm_fixup_long_kernel(const int32_t*
   }
 }
 
+// Both of the above in one launch of 256-thread blocks, for small streams where a launch costs as much as the work:
+// blocks [0, n_long) take one long row each (the block-per-row tree with four waves), every later block four short
+// rows, a wave each (the wave-per-row tree).  A row with a count of zero gets zeros: the rows without nnz ride along.
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void spmm_fixup_both_kernel(const int32_t* __restrict__ fix_row,
+                                                              const int32_t* __restrict__ fix_first,
+                                                              const int32_t* __restrict__ fix_count, int n_long,
+                                                              int64_t n_fix, const T* __restrict__ carry, int ld, int nc,
+                                                              T* __restrict__ out) {
+  constexpr int VEC = VecOf<T>::N;
+  using VT = typename VecOf<T>::type;
+  constexpr int NG = kWave / LPR;
+  constexpr int NW = 4;
+  __shared__ T part[NW][LPR * VPL * VEC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const bool longrow = (int)blockIdx.x < n_long;   // block-uniform
+  const int64_t item = longrow ? (int64_t)blockIdx.x : (int64_t)n_long + ((int64_t)blockIdx.x - n_long) * NW + wv;
+  const bool active = item < n_fix;                // wave-uniform
+  const int64_t first = active ? fix_first[item] : 0;
+  const int n = active ? fix_count[item] : 0;
+  T acc[VPL][VEC];
+#pragma unroll
+  for (int w = 0; w < VPL; ++w)
+#pragma unroll
+    for (int x = 0; x < VEC; ++x) acc[w][x] = T(0);
+  sum_carry_slots<T, LPR, VPL, (VPL == 2 ? 4 : 8)>(carry, first, n, longrow ? wv * NG + gi : gi, longrow ? NW * NG : NG, ld, nc, li, acc);
+#pragma unroll
+  for (int mask = LPR; mask < kWave; mask <<= 1)
+#pragma unroll
+    for (int w = 0; w < VPL; ++w)
+#pragma unroll
+      for (int x = 0; x < VEC; ++x) acc[w][x] += shfl_xor_t(acc[w][x], mask);
+  if (longrow) {
+    if (gi == 0) {
+#pragma unroll
+      for (int w = 0; w < VPL; ++w)
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) part[wv][(w * LPR + li) * VEC + x] = acc[w][x];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int w = 0; w < VPL; ++w)
+#pragma unroll
+      for (int x = 0; x < VEC; ++x) {
+        const int co = (w * LPR + li) * VEC + x;
+        T t = part[0][co];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) t += part[w2][co];
+        acc[w][x] = t;
+      }
+  }
+  if (active && gi == 0) {
+    T* op = out + (int64_t)fix_row[item] * ld;
+#pragma unroll
+    for (int w = 0; w < VPL; ++w) {
+      const int co = (w * LPR + li) * VEC;
+      if (co < nc) {
+        VT o;
+#pragma unroll
+        for (int x = 0; x < VEC; ++x) o.v[x] = acc[w][x];
+        *reinterpret_cast<VT*>(op + co) = o;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Synchronised sweep: X^T.B for the RARE words (the ones the blocked stream leaves uncut: their nnz gather rows of B
 // scattered over the whole table, one 256-byte row from the fabric each, at the ~29 G rows/s the fabric delivers in
