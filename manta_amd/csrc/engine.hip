@@ -1,6 +1,7 @@
 // mnmf engine: context, resident matrix, the three MU solver loops and the C-ABI (include/mnmf.h).
 // gfx950 only.  Host orchestration is deliberately thin: every numeric expression of the reference
 // loops runs in a HIP kernel from spmm.hpp / dense.hpp / gram_mfma.hpp.
+#include <dlfcn.h>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -187,16 +188,60 @@ struct Tune {
 
 constexpr int kLongFix = 32;  // carry lists longer than this are summed by a whole block
 
+// roctx ranges (tracing) without a link-time dependency: MNMF_ROCTX=1 loads the marker library of
+// rocprofiler-sdk (what `rocprofv3 --marker-trace` listens to; libroctx64 as fallback) on first use and brackets every
+// phase of the solver loops -- the host-side window in which the phase's kernels are enqueued -- with a named range.
+struct Roctx {
+  using push_fn = int (*)(const char*);
+  using pop_fn = int (*)();
+  push_fn push = nullptr;
+  pop_fn pop = nullptr;
+  static Roctx& get() {
+    static Roctx r = [] {
+      Roctx x;
+      const char* e = std::getenv("MNMF_ROCTX");
+      if (e && *e && *e != '0') {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+          void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+          if (!h) continue;
+          x.push = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
+          x.pop = reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop"));
+          if (x.push && x.pop) break;
+          x.push = nullptr, x.pop = nullptr;
+        }
+      }
+      return x;
+    }();
+    return r;
+  }
+  bool on() const { return push != nullptr; }
+};
+
 struct PhaseTimer {
   // HIP events on the solver's stream at phase boundaries; summed after the loop has drained.
   static constexpr int kMaxPhases = 8;
+  static constexpr const char* kNames[kMaxPhases] = {"mnmf:gram_w", "mnmf:spmm_xt", "mnmf:h_side", "mnmf:gram_h_kxk",
+                                                     "mnmf:spmm_x", "mnmf:w_update", "mnmf:check", "mnmf:other"};
   hipStream_t s;
   bool on;
+  bool range_open = false;
   std::vector<hipEvent_t> ev;
   std::vector<int> tag;  // phase that ENDS at this event (-1 = start marker)
   PhaseTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {}
-  ~PhaseTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
-  void mark(int phase) {
+  ~PhaseTimer() {
+    close_range();
+    for (auto e : ev) (void)hipEventDestroy(e);
+  }
+  void close_range() {
+    if (range_open) (void)Roctx::get().pop();
+    range_open = false;
+  }
+  // `phase` ends here; `next` (if >= 0) is the phase whose kernels are enqueued from here on
+  void mark(int phase, int next = -1) {
+    if (Roctx::get().on()) {
+      close_range();
+      if (next >= 0 && next < kMaxPhases) range_open = Roctx::get().push(kNames[next]) >= 0;
+    }
     if (!on) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -205,6 +250,7 @@ struct PhaseTimer {
     tag.push_back(phase);
   }
   void collect(double* out /*kMaxPhases*/) {
+    close_range();
     for (int i = 0; i < kMaxPhases; ++i) out[i] = 0.0;
     for (size_t i = 1; i < ev.size(); ++i) {
       if (tag[i] < 0 || tag[i] >= kMaxPhases) continue;
@@ -1823,7 +1869,7 @@ class Engine : public ImplBase {
     LoopClock clk;
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
-    pt.mark(-1);
+    pt.mark(-1, 0);
     std::vector<double> g;
     // The norms of iteration i are read while iteration i+1's SpMMs are already queued (its H update only writes
     // the buffer of h_{i-1}); if iteration i turns out to have converged, that queued work is simply dropped.
@@ -1849,7 +1895,7 @@ class Engine : public ImplBase {
         MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, Gw));  // wT_w       nmf_basic.py:39
         if (sliced) MNMF_TRY(allreduce(Gw, (int64_t)ld * ld));
       }
-      pt.mark(0);
+      pt.mark(0, 1);
       if (eh > 0) {
         xt_cold_event = ev_cold;
         const int r = spmm(Xt, Wc, ld, Nh);                             // (w.T @ in_mat)^T    :40, cold rows first
@@ -1859,7 +1905,7 @@ class Engine : public ImplBase {
       } else {
         MNMF_TRY(spmm(Xt, Wc, ld, Nh));                                 // (w.T @ in_mat)^T    :40
       }
-      pt.mark(1);
+      pt.mark(1, 2);
       if (gw_in_flight) {  // w.T@w of the previous w update: summed over the ranks beside the SpMM above
         E_HIP(hipStreamWaitEvent(ctx->stream, ev_comm_out, 0));
         gw_in_flight = false;
@@ -1903,12 +1949,12 @@ class Engine : public ImplBase {
         // h update :41-42, with h_hT of the new h (:44) and, for the norms, D^T D of D = |h - h_old| (:53) in the same pass
         MNMF_TRY(rk_grams(RK_MU, Hc, Gw, nullptr, nullptr, Hc, Nh, Hn, V, ld, eps, Gh, do_check ? Gd + (size_t)ld * ld : nullptr));
       }
-      pt.mark(2);
+      pt.mark(2, 4);
       MNMF_TRY(spmm(X, Hn, ld, Nw.template as<T>()));                            // in_mat @ h.T         :45
-      pt.mark(4);
+      pt.mark(4, pending ? 6 : 5);
       if (pending) {  // norms of the previous iteration                 :52-53, :62
         const int r = resolve();
-        pt.mark(6);
+        pt.mark(6, 5);
         if (r != 0) {
           (void)clock_stop(clk, stats);
           return r;
@@ -1921,7 +1967,7 @@ class Engine : public ImplBase {
       // w update :46-47, with the next iteration's wT_w (:39) and D^T D of D = |w - w_old| (:52)
       MNMF_TRY(rk_grams(RK_MU, Wc, Gh, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw, do_check ? Gd : nullptr));
       gw_valid = true;
-      pt.mark(5);
+      pt.mark(5, do_check ? 6 : 0);
       // sliced: the next iteration's w.T@w and this iteration's dW Gram in one collective (the dH Gram is computed by
       // every rank from the gathered h); otherwise w.T@w travels with the next k x V partial
       const bool async_gram = sliced && tune.async_gram;
@@ -1948,7 +1994,7 @@ class Engine : public ImplBase {
         }
       }
       MNMF_TRY(rc_comm);
-      if (do_check) pt.mark(6);
+      if (do_check) pt.mark(6, 0);
       cw = 1 - cw;
       ch = 1 - ch;
       ++done;
@@ -2217,7 +2263,7 @@ class Engine : public ImplBase {
     LoopClock clk;
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
-    pt.mark(-1);
+    pt.mark(-1, 0);
     std::vector<double> g;
     // The norm of iteration i is read while iteration i+1's SpMMs are already queued (they only read W_{i+1}); the
     // reference breaks BEFORE assigning w_new (:101-107), so when iteration i turns out to have converged the flip
@@ -2236,20 +2282,20 @@ class Engine : public ImplBase {
       T* Wn = Wb[1 - cw].template as<T>();
       const bool do_check = (fixed > 0) ? (force_check && ((i + 1) % every == 0)) : ((i + 1) % every == 0);
       if (!wtw_valid) MNMF_TRY(gram(Wc, nullptr, Wc, nullptr, m, ld, false, wtw));  // wtw = W.T @ W   :68
-      pt.mark(0);
+      pt.mark(0, 1);
       MNMF_TRY(spmm(Xt, Wc, ld, vtw));                                   // vtw = X.T @ W       :69
-      pt.mark(1);
+      pt.mark(1, 4);
       MNMF_TRY(allreduce_rows(vtw, (int64_t)V * ld + (int64_t)ld * ld, k, ld));
       MNMF_TRY(spmm(X, vtw, ld, pay));                                   // pay = X @ vtw       :72
-      pt.mark(4);
+      pt.mark(4, 3);
       // wt_pay = W.T @ pay (:75) = W.T @ X @ vtw = vtw.T @ vtw: the Gram of the (summed) V x k matrix instead of a
       // product over the m document rows -- symmetric, a tenth of the rows at C3, and in a sharded run every rank
       // computes it from the exchanged vtw, so the second all-reduce of the iteration is gone.
       MNMF_TRY(gram(vtw, nullptr, vtw, nullptr, V, ld, false, wt_pay));
-      pt.mark(3);
+      pt.mark(3, pending ? 6 : 5);
       if (pending) {  // norm of the previous iteration                  :83, :101
         const int r = resolve();
-        pt.mark(6);
+        pt.mark(6, 5);
         if (r != 0) {
           (void)clock_stop(clk, stats);
           return r;
@@ -2265,14 +2311,14 @@ class Engine : public ImplBase {
       // ... with the next iteration's wtw (:68) and D^T D of D = |w_new - W| (:83) in the same pass
       MNMF_TRY(rk_grams(RK_MU_SQRT, Wc, wt_pay, pay, wtw, Wc, pay, Wn, m, ld, eps, wtw, do_check ? Gd : nullptr));
       wtw_valid = true;
-      pt.mark(5);
+      pt.mark(5, do_check ? 6 : 0);
       if (do_check) {
         MNMF_TRY(allreduce(Gd, (int64_t)ld * ld));
         MNMF_TRY(fetch_begin((size_t)ld * ld));
         MNMF_TRY(fetch_add(Gd, (size_t)ld * ld));
         MNMF_TRY(fetch_commit());
         pending = true;
-        pt.mark(6);
+        pt.mark(6, 0);
       }
       cw = 1 - cw;
       ++i;
@@ -2383,7 +2429,7 @@ class Engine : public ImplBase {
     LoopClock clk;
     MNMF_TRY(clock_start(clk));
     PhaseTimer pt(st(), o && o->profile_phases);
-    pt.mark(-1);
+    pt.mark(-1, 2);
     std::vector<double> g;
     const unsigned kb = (unsigned)cdiv((int64_t)gel, 256);
     // k x k chains in one launch each (dense.hpp) while one workgroup is quick enough: measured +14 % / +4 % / +1 %
@@ -2428,18 +2474,18 @@ class Engine : public ImplBase {
         E_LAUNCH();
       }
       MNMF_TRY(rk(RK_PROD, Hc, ST, nullptr, nullptr, nullptr, nullptr, M1, V, ld, 0));  // h.T @ s.T
-      pt.mark(2);
+      pt.mark(2, 4);
       MNMF_TRY(spmm(X, M1, ld, Nw.template as<T>()));                             // in_mat @ (h.T @ s.T)
-      pt.mark(4);
+      pt.mark(4, 3);
       if (!chain) {
         if (!hht_valid) MNMF_TRY(gram(Hc, nullptr, Hc, nullptr, V, ld, false, hhT));  // h @ h.T
-        pt.mark(3);
+        pt.mark(3, pending ? 6 : 5);
         MNMF_TRY(kxk(Sc, hhT, T1, ld, 0, 0));                              // s (h hT)
         MNMF_TRY(kxk(T1, Sc, Dm, ld, 0, 1));                               // s (h hT) sT
       }
       if (pending) {  // norms of the previous iteration                 :179-181, :200
         const int r = resolve();
-        pt.mark(6);
+        pt.mark(6, 5);
         if (r != 0) {
           (void)clock_stop(clk, stats);
           return r;
@@ -2453,11 +2499,11 @@ class Engine : public ImplBase {
       // w update with w1.T @ w1 (:157) and, for the norms, D^T D of D = |w1 - w| (:179) in the same pass
       MNMF_TRY(rk_grams(RK_MU, Wc, Dm, nullptr, nullptr, Wc, Nw.template as<T>(), Wn, m, ld, eps, Gw1, do_check ? Gd : nullptr));
       if (sliced) MNMF_TRY(allreduce(Gw1, (int64_t)gel * (do_check ? 2 : 1)));   // [w1.T@w1 | dW gram]
-      pt.mark(5);
+      pt.mark(5, 0);
       // ---- S update                                                   nmtf.py:156-158
-      pt.mark(0);
+      pt.mark(0, 1);
       MNMF_TRY(spmm(Xt, Wn, ld, Pt));                                    // (w1.T @ in_mat)^T
-      pt.mark(1);
+      pt.mark(1, 3);
       const size_t so = (size_t)s_lo * ld;   // this rank's slice of the vocabulary rows (everything when not sliced)
       if (sliced) {
         MNMF_TRY(reduce_scatter_rows(Pt, k, ld));
@@ -2476,7 +2522,7 @@ class Engine : public ImplBase {
         kxk_mu_kernel<T><<<kb, 256, 0, st()>>>(Sc, num_s, den_s, (T)eps, Sn, ld);
         E_LAUNCH();
       }
-      pt.mark(3);
+      pt.mark(3, 2);
       // ---- H update                                                   nmtf.py:161-163
       MNMF_TRY(rk(RK_PROD, Pt + so, Sn, nullptr, nullptr, nullptr, nullptr, M1 + so, s_rows, ld, 0));  // (s1.T @ P)^T = Pt s1
       if (!chain) {
@@ -2493,7 +2539,7 @@ class Engine : public ImplBase {
         MNMF_TRY(rk_grams(RK_MU, Hc, Qm, nullptr, nullptr, Hc, M1, Hn, V, ld, eps, hhT, do_check ? Gd + gel : nullptr));
       }
       hht_valid = true;
-      pt.mark(2);
+      pt.mark(2, do_check ? 6 : 2);
       if (do_check) {                                                     // Frobenius norms   nmtf.py:179-181
         if (!sliced) MNMF_TRY(allreduce(Gd, (int64_t)gel));
         MNMF_TRY(fetch_begin(4 * gel));
@@ -2501,7 +2547,7 @@ class Engine : public ImplBase {
         MNMF_TRY(fetch_add(Sb[0], 2 * gel));       // both S buffers: ||s1 - s||_F on the host
         MNMF_TRY(fetch_commit());
         pending = true;
-        pt.mark(6);
+        pt.mark(6, 2);
       }
       cw = 1 - cw;
       ch = 1 - ch;

@@ -386,3 +386,39 @@ def test_wide_address_variant_of_the_spmm(golden, dtype, monkeypatch):
         assert np.array_equal(a, b)
     assert rel(res["1"][0], g["X"] @ B) <= (1e-12 if dtype == "fp64" else 2e-6)
     assert rel(res["1"][1], g["X"].T @ A) <= (1e-12 if dtype == "fp64" else 2e-6)
+
+
+def test_roctx_ranges_do_not_change_results(golden, tmp_path):
+    """MNMF_ROCTX=1 (tracing): the marker library is loaded with dlopen on first use and every solver phase is
+    bracketed by a named range (what `rocprofv3 --marker-trace` records, profiles/r03_roctx_c1_marker_stats.csv).  The
+    switch is read once per process, hence a child process; its factors must equal this process's bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    from manta_amd.engine import Engine
+
+    g = golden("fixed_A_300x200_k5")
+    out = tmp_path / "w.npy"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the child has no conftest: hand the matrix over as arrays
+    X = g["X"].tocsr()
+    np.savez(tmp_path / "in.npz", data=X.data, indices=X.indices, indptr=X.indptr, shape=np.array(X.shape), W0=g["W0"], H0=g["H0"])
+    code = (
+        "import sys, numpy as np, scipy.sparse as sp; sys.path.insert(0, %r)\n"
+        "from manta_amd.engine import Engine\n"
+        "d = np.load(%r)\n"
+        "X = sp.csr_matrix((d['data'], d['indices'], d['indptr']), shape=tuple(d['shape']))\n"
+        "e = Engine(dtype='fp64'); e.set_matrix(X)\n"
+        "W, H, s = e.run_nmf(d['W0'], d['H0'], fixed_iters=10, force_check=True)\n"
+        "np.save(%r, W.detach().cpu().numpy()); e.close(); print('OK')\n" % (root, str(tmp_path / "in.npz"), str(out))
+    )
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MNMF_ROCTX="1"), capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    e = Engine(dtype="fp64")
+    try:
+        e.set_matrix(X)
+        W, H, s = e.run_nmf(g["W0"], g["H0"], fixed_iters=10, force_check=True)
+        assert np.array_equal(np.load(out), W.detach().cpu().numpy())
+    finally:
+        e.close()
