@@ -25,6 +25,10 @@ def main():
     is_hot = torch.zeros(V, dtype=torch.bool, device=dev)
     is_hot[order[:n_hot]] = True
     keep = is_hot[col.long()] if which == "hot" else ~is_hot[col.long()]
+    if which == "cold_even":   # half of the cold vocabulary: what one of two XCD groups would gather from
+        rank = torch.empty(V, dtype=torch.long, device=dev)
+        rank[order] = torch.arange(V, device=dev)
+        keep &= (rank[col.long()] % 2 == 0)
     rows = torch.repeat_interleave(torch.arange(m, device=dev), rowptr[1:] - rowptr[:-1])
     cnt = torch.bincount(rows[keep], minlength=m)
     rp = torch.zeros(m + 1, dtype=torch.int64, device=dev)
