@@ -40,9 +40,11 @@ def test_sweep_fixed_iterations_bit_identical_to_single_runs(eng, golden, ks):
         W1, H1, s1 = eng.run_nmf(W0, H0, fixed_iters=25, force_check=True, zero_threshold=1e-5)
         assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
         assert s.iters == s1.iters == 25 and s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
-    # and against the CPU oracle within the fp32 tolerance
-    want = oc.basic_nmf(X, st[0][0].copy(), st[0][1].copy(), zero_threshold=1e-5, n_iter=25, check=False)
-    assert np.linalg.norm(host(got[0][0]) - want["W"]) <= 1e-4 * np.linalg.norm(want["W"])
+    # and every problem against the CPU oracle within the fp32 tolerance
+    for (W0, H0), (W, H, s) in zip(st, got):
+        want = oc.basic_nmf(X, W0.copy(), H0.copy(), zero_threshold=1e-5, n_iter=25, check=False)
+        assert np.linalg.norm(host(W) - want["W"]) <= 1e-4 * np.linalg.norm(want["W"])
+        assert np.linalg.norm(host(H) - want["H"]) <= 1e-4 * np.linalg.norm(want["H"])
 
 
 def test_sweep_each_problem_stops_at_its_own_iteration(eng, golden):
@@ -150,9 +152,10 @@ def test_sweep_fp64_bit_identical_to_single_runs(golden, ks):
             W1, H1, s1 = e64.run_nmf(W0, H0, fixed_iters=20, force_check=True, zero_threshold=1e-5)
             assert np.array_equal(host(W), host(W1)) and np.array_equal(host(H), host(H1))
             assert s.iters == s1.iters == 20 and s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
-        want = oc.basic_nmf(X, st[-1][0].copy(), st[-1][1].copy(), zero_threshold=1e-5, n_iter=20, check=False)
-        assert np.linalg.norm(host(got[-1][0]) - want["W"]) <= 1e-10 * np.linalg.norm(want["W"])
-        assert np.linalg.norm(host(got[-1][1]) - want["H"]) <= 1e-10 * np.linalg.norm(want["H"])
+        for (W0, H0), (W, H, s) in zip(st, got):
+            want = oc.basic_nmf(X, W0.copy(), H0.copy(), zero_threshold=1e-5, n_iter=20, check=False)
+            assert np.linalg.norm(host(W) - want["W"]) <= 1e-10 * np.linalg.norm(want["W"])
+            assert np.linalg.norm(host(H) - want["H"]) <= 1e-10 * np.linalg.norm(want["H"])
         # staggered stopping under the reference's rule
         g2 = golden("converged_D_600x500_k6_nmf")
         e64.set_matrix(g2["X"])
