@@ -5,7 +5,7 @@ Only the solver path is here: ``run_nmf`` with the referen
 synthetic TF-IDF generator.  Importing the package does not load the HIP library; using the engine
 without it (or without a GPU) raises.
 """
-from .nmf import find_max_rank, install, run_nmf, run_nmf_sweep  # noqa: F401
+from .nmf import find_max_rank, install, run_nmf, run_nmf_sweep, sweeping_run_nmf  # noqa: F401
 
-__all__ = ["run_nmf", "run_nmf_sweep", "install", "find_max_rank"]
+__all__ = ["run_nmf", "run_nmf_sweep", "sweeping_run_nmf", "install", "find_max_rank"]
 __version__ = "0.1.0"

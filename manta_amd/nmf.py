@@ -252,7 +252,61 @@ def run_nmf_sweep(sparse_matrix, topic_counts, init: Callable = nmf_initializati
     return results
 
 
-def install(tfidf: bool = False, init=None) -> list:
+def sweeping_run_nmf(topic_counts, init=None):
+    """A ``run_nmf`` for callers that loop over topic counts themselves -- OptimizationPipeline.run_optimization calls
+    ``run_nmf(num_of_topics=k, sparse_matrix=X, norm_thresh=0.005, nmf_method=...)`` once per candidate
+    (optimization_pipeline.py:105-136, 193-198) -- and cannot be handed ``run_nmf_sweep``: told the counts of the sweep
+    up front, the first standard-NMF call with one of them factorises ALL of them through ``run_nmf_sweep`` (one pass over
+    X per SpMM for the counts that share a padded factor row) and keeps the results; the later calls with the same
+    matrix and arguments are answered from there.  Every answer equals the plain ``run_nmf`` call bit for bit (the
+    starts are drawn per count, in the order of ``topic_counts``, as the loop would).  Anything else -- another method,
+    explicit starts, a count that was not announced, a result already handed out -- goes to ``run_nmf``.
+
+    ``init``: as in ``install``.  The returned function has ``.stats``, the per-count statistics of the last batch."""
+    import functools
+    import inspect
+
+    planned = [int(k) for k in topic_counts]
+    if not planned or any(k <= 0 for k in planned):
+        raise ValueError("sweeping_run_nmf: topic_counts must be positive integers")
+    sig = inspect.signature(run_nmf)
+    state = {"key": None, "results": {}}
+
+    @functools.wraps(run_nmf)
+    def target(*args, **kw):
+        b = sig.bind(*args, **kw)
+        explicit_init = "init" in b.arguments
+        b.apply_defaults()
+        a = b.arguments
+        if init is not None and not explicit_init:
+            a["init"] = init
+        k = a["num_of_topics"]
+        plain = (a["nmf_method"] == "nmf" and isinstance(k, (int, np.integer)) and int(k) in planned and
+                 a["W0"] is None and a["H0"] is None and a["stats_out"] is None)
+        if not plain:
+            return run_nmf(**a)
+        mkey = _matrix_key(a["sparse_matrix"])
+        init_id = a["init"] if isinstance(a["init"], str) else id(a["init"])
+        key = (mkey, init_id, a["norm_thresh"], a["zero_threshold"], a["dtype"], a["device"], a["max_iter"],
+               a["fixed_iters"], a["check_every"], a["seed"])
+        if mkey is None or state["key"] != key or int(k) not in state["results"]:
+            stats = []
+            outs = run_nmf_sweep(a["sparse_matrix"], planned, init=a["init"], norm_thresh=a["norm_thresh"],
+                                 zero_threshold=a["zero_threshold"], nmf_method="nmf", dtype=a["dtype"], device=a["device"],
+                                 max_iter=a["max_iter"], fixed_iters=a["fixed_iters"], check_every=a["check_every"],
+                                 seed=a["seed"], stats_out=stats)
+            state["key"] = key if mkey is not None else None
+            state["results"] = {}
+            for kk, o in zip(planned, outs):
+                state["results"].setdefault(kk, o)      # a count announced twice: the first factorisation
+            target.stats = dict(zip(planned, stats))
+        return state["results"].pop(int(k))             # handed out once: the caller owns the arrays
+
+    target.stats = {}
+    return target
+
+
+def install(tfidf: bool = False, init=None, sweep_counts=None) -> list:
     """Rebind ``run_nmf`` inside an installed MANTA.  Callers bind the name at import time
     (modeling_pipeline.py:10, optimization_pipeline.py:16), so the attribute is replaced on each
     importing module.  ``tfidf=True`` also rebinds ``tf_idf_english`` / ``tf_idf_turkish`` where they are bound
@@ -260,14 +314,18 @@ def install(tfidf: bool = False, init=None) -> list:
     the GPU whenever the caller passes no ``init`` of its own (MANTA's pipelines never do, modeling_pipeline.py:62-67):
     the host ``svds`` the reference uses takes 1-12 s on matrices whose whole factorisation takes 0.02-0.6 s here
     (tools/e2e_small.py); the start then agrees with the reference's to ~1e-6 instead of bit for bit.
+    ``sweep_counts=[5, 10, 15, ...]``: the topic counts a following ``run_optimization`` will try -- its per-count
+    ``run_nmf`` calls are then served by one batched factorisation (``sweeping_run_nmf``).
     Returns the module names that were patched."""
     import functools
     import importlib
 
     target = run_nmf
-    if init is not None:
-        if init not in ("device", "device_random"):
-            raise ValueError("install(init=...): 'device' or 'device_random'")
+    if init is not None and init not in ("device", "device_random"):
+        raise ValueError("install(init=...): 'device' or 'device_random'")
+    if sweep_counts is not None:
+        target = sweeping_run_nmf(sweep_counts, init=init)
+    elif init is not None:
 
         @functools.wraps(run_nmf)
         def target(num_of_topics, sparse_matrix, *args, **kw):

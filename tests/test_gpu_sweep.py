@@ -208,3 +208,34 @@ def test_sweep_bit_identical_on_the_lds_paths(golden, monkeypatch):
                 assert s.w_norm == s1.w_norm and s.h_norm == s1.h_norm
         finally:
             e.close()
+
+
+def test_sweeping_run_nmf_serves_a_callers_loop(golden):
+    """``install(sweep_counts=...)`` / ``sweeping_run_nmf``: MANTA's optimisation pipeline calls run_nmf once per topic
+    count with keywords (optimization_pipeline.py:193-198); the stand-in factorises the announced counts in one batch at
+    the first call and answers the others from it -- every answer bit-identical to the plain call."""
+    import manta_amd
+
+    g = golden("converged_D_600x500_k6_nmf")
+    X = g["X"]
+    ks = [4, 6, 5]
+    starts = {k: s for k, s in zip(ks, starts_for(X, ks, 21))}
+
+    def init(csc, k):                 # deterministic per count, as nmf_initialization_nndsvd is
+        return starts[k][0].copy(), starts[k][1].copy()
+
+    f = manta_amd.sweeping_run_nmf(ks)
+    outs = [f(num_of_topics=k, sparse_matrix=X, init=init, norm_thresh=0.005, nmf_method="nmf") for k in ks]
+    assert sorted(f.stats) == sorted(ks) and all(f.stats[k]["batch"] == ks for k in ks)     # one batch (4 + 6 + 5 <= 16)
+    for k, out in zip(ks, outs):
+        want = manta_amd.run_nmf(k, X, init=init, norm_thresh=0.005)
+        assert np.array_equal(out["W"], want["W"]) and np.array_equal(out["H"], want["H"])
+    # a second round over the same counts is a second batch; other methods and unannounced counts go straight through
+    again = f(num_of_topics=6, sparse_matrix=X, init=init, norm_thresh=0.005, nmf_method="nmf")
+    assert np.array_equal(again["W"], outs[1]["W"])
+    other = f(num_of_topics=3, sparse_matrix=X, init=lambda c, k: (starts[4][0][:, :3].copy(), starts[4][1][:3].copy()), norm_thresh=0.005)
+    assert other["W"].shape[1] == 3
+    p = f(4, X, init, 0.005, 0.00001, "pnmf")
+    assert sorted(p) == ["H", "W"] and p["W"].shape[1] == 4
+    with pytest.raises(ValueError):
+        manta_amd.sweeping_run_nmf([])
