@@ -42,7 +42,7 @@ def run_with_heartbeat(cmd, env, timeout=300):
 STALLED = []   # set once a shared-GPU launch did not finish: the later ones are skipped straight away
 
 
-def run_shared_gpu(cmd, env, limit=170):
+def run_shared_gpu(cmd, env, limit=130):   # two launches of one test stay under a 300 s per-test limit
     """Run a command that puts several processes on the ONE GPU of the test box.  Such runs are erratic here -- the same
     launch takes 3 s or 100 s, and now and then does not finish at all (time-sliced queues, cross-stream waits) -- and
     that says nothing about the code under test: a run still going after `limit` seconds is a SKIP (and so are the
