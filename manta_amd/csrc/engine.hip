@@ -817,6 +817,27 @@ class Engine : public ImplBase {
       s.fix_first.swap(f);
       s.fix_count.swap(c);
     }
+    // X^T beside a tile or sweep stream: the rows those streams write need no zeroing -- at configs[1] that is all but
+    // a handful of the 95k "rows without nnz" of the blocked stream (24 MB of zeros per X^T.W that were overwritten
+    // right away).  The tile stream owns the rows of the words with a piece in some tile, the sweep those of its word table.
+    if (&M == &Xt && !s.empty_rows.empty() && (Xth.nnz > 0 || Xs.nnz > 0)) {
+      std::vector<char> owned((size_t)M.rows, 0);
+      if (Xth.nnz > 0)
+        for (int32_t r : Xth.pieces.row)   // the words that have a piece in some tile
+          if (r >= 0 && r < M.rows) owned[(size_t)r] = 1;
+      if (Xs.nnz > 0) {
+        std::vector<int32_t> words((size_t)Xs.rpp * Xs.P);
+        E_HIP(hipMemcpyAsync(words.data(), Xs.words.p, words.size() * 4, hipMemcpyDeviceToHost, st()));
+        E_HIP(hipStreamSynchronize(st()));
+        for (int32_t w : words)
+          if (w >= 0 && w < M.rows) owned[(size_t)w] = 1;
+      }
+      std::vector<int32_t> keep;
+      for (int32_t r : s.empty_rows)
+        if (!owned[(size_t)r]) keep.push_back(r);
+      s.empty_rows.swap(keep);
+      M.n_empty = (int64_t)s.empty_rows.size();
+    }
     // Small streams that are alone on their output (X; X^T without a tile or sweep stream beside it): one fix-up launch
     // for everything, and the rows without nnz join it as rows with no carry slots instead of a zeroing launch of their
     // own in front of the stream kernel.
